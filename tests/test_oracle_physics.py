@@ -206,8 +206,15 @@ def test_joint_limit_rows(model, oracle64):
     orc.substep(s)
     assert orc.limit_rows(s) == 25
     qd = orc.get_state(s)[38:63]
-    # ERP 0.2 pushes each joint back at >= 0.2*0.05/dt = 5 rad/s (PGS couples them, so allow slack)
-    assert np.all(qd > 2.0)
+    # ERP 0.2 asks each joint for >= 0.2*0.05/dt = 5 rad/s. 60 PGS sweeps are not converged on the
+    # ill-conditioned neck chain (947 kg cranium behind 12 kg atlas), so most - not all - are there;
+    assert np.sum(np.abs(qd - 5.0) < 0.1) >= 20
+    # the converged solution satisfies every unilateral row.
+    orc.set_param("iterations", 6000)
+    orc.set_state(s, st)
+    orc.substep(s)
+    orc.set_param("iterations", 60)
+    assert np.all(orc.get_state(s)[38:63] > 5.0 - 1e-2)
 
 
 def test_f32_oracle_tracks_f64(model, oracle64, oracle32):
