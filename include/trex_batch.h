@@ -1,0 +1,150 @@
+/*
+ * trex_batch.h - C-ABI of the MI355X-native batched physics step for the T-rex gym env.
+ *
+ * This is the drop-in boundary for ONE path of bingjeff/trex-gym: everything that
+ * TrexBulletEnv.step()/reset() delegates to the physics engine and the robot adapter
+ * (boundary 3).  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative TREX_E_* code on failure;
+ *     trex_last_error() returns a thread-local message for the last failure
+ *     (pybullet raises pybullet.error at the same call sites [EXT]).
+ *   - a TrexModel is immutable after trex_batch_create() has consumed it and may be
+ *     shared by several batches; a TrexBatch is bound to one HIP device, is not re-entrant,
+ *     and all of its calls are asynchronous and ordered on the hipStream_t given
+ *     (passed as void* so the header needs no HIP include; NULL = the default stream).
+ *   - "device" pointers are caller-owned HIP device buffers (e.g. torch tensors' data_ptr()).
+ *   - joints are always exposed in the reference's observation order: revolute joint names
+ *     sorted (trex_robot.py:311-314); J = trex_model_num_joints() (25 for trex.urdf).
+ */
+#ifndef TREX_BATCH_H
+#define TREX_BATCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default)
+
+#define TREX_OK 0
+#define TREX_E_INVALID (-1)   /* bad argument (null pointer, unknown name, size mismatch) */
+#define TREX_E_IO (-2)        /* file missing / unreadable */
+#define TREX_E_PARSE (-3)     /* malformed URDF / mesh */
+#define TREX_E_UNSUPPORTED (-4) /* model outside what the kernels handle (>26 bodies, joint type) */
+#define TREX_E_HIP (-5)       /* HIP runtime error, no device */
+
+typedef struct TrexModel TrexModel;
+typedef struct TrexBatch TrexBatch;
+
+const char *trex_last_error(void);
+
+/* ---- model: replaces loadURDF + the getJointInfo/getDynamicsInfo/getNumJoints introspection
+ *      of trex_robot.py:47-56,98-117,158,175-187,294-320 and the floor of trex_env.py:103 ---- */
+
+/* Parse a URDF (fixed + revolute joints), merge fixed joints, attach collision hulls.
+ * collisions_dir: NULL -> use the URDF's own <collision><mesh .obj>; otherwise a directory of
+ * COL_*_convex_hull.dae hulls placed with the <visual><origin> of the same-named mesh (this is
+ * how the reference's own assets/trex.urdf, which has no <collision>, is loaded). */
+int trex_model_load(const char *urdf_path, const char *collisions_dir, TrexModel **out);
+void trex_model_destroy(TrexModel *model);
+
+int trex_model_num_bodies(const TrexModel *model);      /* 26: moving bodies after the merge */
+int trex_model_num_joints(const TrexModel *model);      /* 25: actuated revolute joints */
+int trex_model_num_urdf_joints(const TrexModel *model); /* 132 = pybullet getNumJoints (trex_robot.py:158) */
+int trex_model_num_hull_vertices(const TrexModel *model);
+double trex_model_total_mass(const TrexModel *model, int include_base_link); /* trex_robot.py:318-320 sums without the base link */
+
+/* k-th joint in observation order: name, pybullet joint index (trex_robot.py:314), limits
+ * (trex_robot.py:337-346). Any out pointer may be NULL. */
+int trex_model_joint_info(const TrexModel *model, int k, const char **name, int *urdf_joint_index,
+                          double *lower, double *upper);
+
+/* reset configuration (trex_env.py:81-87, trex_robot.py:305-308). Accepts the URDF joint name
+ * or the pre-rename spelling ("femur_L_joint"). Unknown joint -> TREX_E_INVALID (the reference
+ * raises KeyError there). Must be called before trex_batch_create. */
+int trex_model_set_start_angle(TrexModel *model, const char *joint_name, double angle);
+int trex_model_set_start_pose(TrexModel *model, const double xyz[3], const double rpy[3]); /* trex_env.py:105-106 */
+
+/* engine parameters: "dt" "substeps" "iterations" "gravity" "motor_kp" "motor_kd" "motor_max_force"
+ * "floor_z" "friction" "erp" "contact_erp" "contact_margin" "link_damping"
+ * "max_coordinate_velocity" "max_contacts"  (setTimeStep / setPhysicsEngineParameter / setGravity,
+ * trex_env.py:115-117; motor gains trex_robot.py:260,401,421). */
+int trex_model_set_param(TrexModel *model, const char *name, double value);
+int trex_model_get_param(const TrexModel *model, const char *name, double *value);
+
+/* Introspection of the compiled model for tests: copies the named array as doubles, returns the
+ * element count (or a negative error). Names: "parent" "depth" "joint_axis" "joint_pos" "joint_rot"
+ * "q_lower" "q_upper" "joint_damping" "mass" "com" "inertia" "obs_order" "head_body" "head_point"
+ * "hull_xyz" "hull_start" "sphere_center" "sphere_radius" "q_start" "base_start_pos"
+ * "base_start_quat" "revolute_joint_indices". */
+int trex_model_get_array(const TrexModel *model, const char *name, double *out, int capacity);
+
+/* ---- batch: N independent env copies resident on one GPU ---- */
+
+int trex_batch_create(const TrexModel *model, int num_envs, int device, TrexBatch **out);
+void trex_batch_destroy(TrexBatch *batch);
+int trex_batch_num_envs(const TrexBatch *batch);
+
+/* reward weights (trex_env.py:42-44): distance, energy, drift. Defaults 1.0, 0.005, 0.002. */
+int trex_batch_set_reward_weights(TrexBatch *batch, float distance, float energy, float drift);
+
+/* TrexBulletEnv.reset (trex_env.py:98-122): envs with mask[n] != 0 (all if mask == NULL) go to the
+ * start pose with motors disabled and take ONE un-actuated substep. obs_out (device, [N, 3J],
+ * nullable) receives the observation of every env (reset or not). */
+int trex_batch_reset(TrexBatch *batch, const uint8_t *mask_dev, float *obs_out_dev, void *stream);
+
+/* TrexBulletEnv.step (trex_env.py:128-154) for all N envs in ONE kernel launch:
+ * clip(actions) -> substeps x [position motors + physics substep] -> obs, reward, done.
+ *   actions_dev   [N, J]  f32 device, joint targets in observation order
+ *   obs_dev       [N, 3J] f32 device: q, qd, appliedJointMotorTorque (trex_robot.py:365)
+ *   reward_dev    [N]     f32 device (trex_env.py:192)
+ *   done_dev      [N]     u8 device, always 0 (trex_env.py:183-184)
+ *   penalties_dev [N, 3]  f32 device, nullable: lifting_com, station_keeping, energy
+ *                         (the three values logged at trex_env.py:193-195) */
+int trex_batch_step(TrexBatch *batch, const float *actions_dev, float *obs_dev, float *reward_dev,
+                    uint8_t *done_dev, float *penalties_dev, void *stream);
+
+/* env state [N, 13 + 2J] f32 device: base position(3), base orientation quaternion xyzw(4) - both
+ * of the base INERTIAL frame as resetBasePositionAndOrientation/getBasePositionAndOrientation
+ * (trex_robot.py:63,327) - base linear(3) and angular(3) world velocity, q(J), qd(J). */
+int trex_batch_get_state(TrexBatch *batch, float *state_dev, void *stream);
+int trex_batch_set_state(TrexBatch *batch, const float *state_dev, void *stream);
+/* motors stay disabled after reset until the first step (trex_robot.py:309); set_state keeps the
+ * flag, this call forces it (tests). */
+int trex_batch_set_motors_enabled(TrexBatch *batch, int enabled, void *stream);
+
+/* world position of the head link COM, [N,3] (trex_robot.py:330-335). */
+int trex_batch_head_position(TrexBatch *batch, float *out_dev, void *stream);
+
+/* domain randomisation (BASELINE config 5; no reference counterpart): per-env mass scale of each
+ * moving body [N, num_bodies] and per-env friction coefficient [N]; either may be NULL. */
+int trex_batch_set_domain(TrexBatch *batch, const float *mass_scale_dev, const float *friction_dev,
+                          void *stream);
+
+/* diagnostics of the last substep: contact count per env [N] i32 (nullable), summed normal
+ * impulse per env [N] f32 (nullable). */
+int trex_batch_contact_stats(TrexBatch *batch, int32_t *count_dev, float *normal_impulse_dev, void *stream);
+
+/* Diagnostics for the parity tests: one step like trex_batch_step, additionally dumping env 0's
+ * intermediates of its LAST substep into debug_dev (4096 f32 device): [0,32) qdd per body lane,
+ * [32,38) base spatial acceleration, [64,96) generalised velocity before the constraint solve
+ * per dof lane, [96,128) its PGS correction, [128] contact count, [129] limit-row mask,
+ * [160,960) the 25 joint columns of M^-1, [960+16c ..) per contact body,x,y,z,dist,1/diag(3),rhs(3),
+ * lambda(3), [1216+32(3c+a) ..) the contact rows' response vectors. Not part of the product path. */
+int trex_batch_debug_step(TrexBatch *batch, const float *actions_dev, float *obs_dev, float *debug_dev, void *stream);
+
+/* Launch geometry + bytes, for bench.py: fills grid, block, lds bytes, algorithmic bytes/env-step. */
+int trex_batch_launch_info(const TrexBatch *batch, int *grid, int *block, int *lds_bytes,
+                           int *alg_bytes_per_env_step);
+
+/* Times `steps` trex_batch_step launches with hipEvents on `stream` (the stream the kernels run on)
+ * and returns the average per-launch duration in milliseconds. */
+int trex_batch_time_steps(TrexBatch *batch, const float *actions_dev, float *obs_dev, float *reward_dev,
+                          uint8_t *done_dev, int steps, void *stream, float *avg_ms_out);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* TREX_BATCH_H */

@@ -1,0 +1,413 @@
+// C-ABI of include/trex_batch.h: model handle, batch handle, stream-ordered launches.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/trex_batch.h"
+#include "device_model.h"
+#include "model.hpp"
+
+extern "C" {
+hipError_t trex_launch_step(const TrexDeviceModel *, TrexBatchArrays, int, const float *, float *, float *, uint8_t *,
+                            float *, float, float, float, float *, hipStream_t);
+hipError_t trex_launch_reset(const TrexDeviceModel *, TrexBatchArrays, int, const uint8_t *, float *, float, float,
+                             float, float *, hipStream_t);
+hipError_t trex_launch_pack_state(const TrexDeviceModel *, TrexBatchArrays, int, float *, int, hipStream_t);
+hipError_t trex_launch_head(const TrexDeviceModel *, TrexBatchArrays, int, float *, hipStream_t);
+hipError_t trex_launch_fill(float *, float, int, hipStream_t);
+hipError_t trex_launch_fill_u8(uint8_t *, uint8_t, int, hipStream_t);
+hipError_t trex_launch_copy_mass_scale(const float *, float *, int, int, hipStream_t);
+int trex_step_lds_bytes(void);
+}
+
+struct TrexModel {
+  trex::HostModel host;
+};
+
+struct TrexBatch {
+  int n = 0, device = 0, nb = 0, nj = 0;
+  TrexDeviceModel *dmodel = nullptr;
+  TrexBatchArrays arr{};
+  float wd = 1.0f, we = 0.005f, wk = 0.002f;  // trex_env.py:42-44
+  std::vector<void *> allocs;
+};
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string &msg) {
+  g_error = msg;
+  return code;
+}
+int hip_fail(hipError_t e, const char *what) {
+  return fail(TREX_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                  \
+  do {                                                 \
+    hipError_t _e = (expr);                            \
+    if (_e != hipSuccess) return hip_fail(_e, #expr);  \
+  } while (0)
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok;
+  explicit DeviceGuard(int dev) {
+    ok = hipGetDevice(&prev) == hipSuccess && (prev == dev || hipSetDevice(dev) == hipSuccess);
+    if (prev == dev) prev = -1;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+void fill_device_model(const trex::HostModel &h, TrexDeviceModel &d) {
+  std::memset(&d, 0, sizeof d);
+  d.nb = h.nb;
+  d.head_body = h.head_body;
+  d.nv = (int)h.hull_xyz.size();
+  const trex::Params &p = h.prm;
+  const double prm[TP_COUNT] = {p.dt, p.substeps, p.iterations, p.gravity, p.motor_kp, p.motor_kd, p.motor_max_force,
+                                p.floor_z, p.friction, p.erp, p.contact_erp, p.contact_margin, p.link_damping,
+                                p.max_coordinate_velocity, p.max_contacts};
+  for (int i = 0; i < TP_COUNT; i++) d.prm[i] = (float)prm[i];
+  d.head_point[0] = (float)h.head_point.x; d.head_point[1] = (float)h.head_point.y; d.head_point[2] = (float)h.head_point.z;
+  d.base_pos0[0] = (float)h.base_start_pos.x; d.base_pos0[1] = (float)h.base_start_pos.y; d.base_pos0[2] = (float)h.base_start_pos.z;
+  for (int c = 0; c < 4; c++) d.base_quat0[c] = (float)h.base_start_quat[c];
+  int maxdepth = 0;
+  for (int l = 0; l < TREX_TL; l++) {
+    d.parent[l] = -1; d.depth[l] = -1; d.obs_slot[l] = -1;
+    for (int k = 0; k < TREX_MAXD; k++) d.anc[k][l] = -1;
+    for (int k = 0; k < TREX_MAXCH; k++) d.child[k][l] = -1;
+    d.mass[l] = 1.0f;
+    d.jrot[0][l] = d.jrot[4][l] = d.jrot[8][l] = 1.0f;
+    d.axis[2][l] = 1.0f;
+    d.inertia[0][l] = d.inertia[3][l] = d.inertia[5][l] = 1.0f;
+  }
+  for (int b = 0; b < h.nb; b++) {
+    d.parent[b] = h.parent[b];
+    d.depth[b] = h.depth[b];
+    maxdepth = std::max(maxdepth, h.depth[b]);
+    for (int i = b; i > 0; i = h.parent[i]) d.anc[h.depth[i] - 1][b] = i;
+    if (b > 0) {
+      int p = h.parent[b];
+      for (int k = 0; k < TREX_MAXCH; k++)
+        if (d.child[k][p] < 0) { d.child[k][p] = b; break; }
+    }
+    const trex::Vec3 &a = h.joint_axis[b], &jp = h.joint_pos[b], &c = h.com[b], &sc = h.sphere_center[b];
+    d.axis[0][b] = (float)a.x; d.axis[1][b] = (float)a.y; d.axis[2][b] = (float)a.z;
+    d.jpos[0][b] = (float)jp.x; d.jpos[1][b] = (float)jp.y; d.jpos[2][b] = (float)jp.z;
+    d.com[0][b] = (float)c.x; d.com[1][b] = (float)c.y; d.com[2][b] = (float)c.z;
+    for (int k = 0; k < 9; k++) d.jrot[k][b] = (float)h.joint_rot[b].m[k];
+    for (int k = 0; k < 6; k++) d.inertia[k][b] = (float)h.inertia[b][k];
+    d.mass[b] = (float)h.mass[b];
+    d.lower[b] = (float)h.q_lower[b]; d.upper[b] = (float)h.q_upper[b]; d.damp[b] = (float)h.joint_damping[b];
+    d.q_start[b] = (float)h.q_start[b];
+    d.sphere[0][b] = (float)sc.x; d.sphere[1][b] = (float)sc.y; d.sphere[2][b] = (float)sc.z;
+    d.sphere[3][b] = (float)h.sphere_radius[b];
+    d.hull_start[b] = h.hull_start[b];
+  }
+  for (int b = h.nb; b <= TREX_TL; b++) d.hull_start[b] = h.hull_start[h.nb];
+  d.maxdepth = maxdepth;
+  for (size_t k = 0; k < h.obs_order.size(); k++) d.obs_slot[h.obs_order[k]] = (int)k;
+  // dof lane l in chain of body b?  joint lanes: b is l or a descendant of l; base dof lanes: every body
+  for (int l = 0; l < TREX_TL; l++) {
+    unsigned m = 0;
+    if (l >= 1 && l < h.nb) {
+      for (int b = 0; b < h.nb; b++)
+        for (int i = b; i > 0; i = h.parent[i])
+          if (i == l) { m |= 1u << b; break; }
+    } else if (l >= h.nb && l < h.nb + 6) {
+      m = (h.nb >= 32) ? 0xffffffffu : ((1u << h.nb) - 1u);
+    }
+    d.desc_mask[l] = m;
+  }
+}
+
+int check_batch(const TrexBatch *b) { return b ? TREX_OK : fail(TREX_E_INVALID, "null batch"); }
+
+}  // namespace
+
+extern "C" {
+
+const char *trex_last_error(void) { return g_error.c_str(); }
+
+int trex_model_load(const char *urdf_path, const char *collisions_dir, TrexModel **out) {
+  if (!urdf_path || !out) return fail(TREX_E_INVALID, "trex_model_load: null argument");
+  *out = nullptr;
+  int code = TREX_OK;
+  try {
+    auto m = std::make_unique<TrexModel>();
+    m->host = trex::load_model(urdf_path, collisions_dir, &code);
+    *out = m.release();
+    return TREX_OK;
+  } catch (const std::exception &e) {
+    return fail(code ? code : TREX_E_PARSE, e.what());
+  }
+}
+
+void trex_model_destroy(TrexModel *m) { delete m; }
+
+int trex_model_num_bodies(const TrexModel *m) { return m ? m->host.nb : fail(TREX_E_INVALID, "null model"); }
+int trex_model_num_joints(const TrexModel *m) { return m ? m->host.nb - 1 : fail(TREX_E_INVALID, "null model"); }
+int trex_model_num_urdf_joints(const TrexModel *m) { return m ? m->host.num_urdf_joints : fail(TREX_E_INVALID, "null model"); }
+int trex_model_num_hull_vertices(const TrexModel *m) { return m ? (int)m->host.hull_xyz.size() : fail(TREX_E_INVALID, "null model"); }
+double trex_model_total_mass(const TrexModel *m, int include_base_link) {
+  if (!m) return -1.0;
+  return include_base_link ? m->host.total_mass : m->host.total_mass_excluding_base;
+}
+
+int trex_model_joint_info(const TrexModel *m, int k, const char **name, int *urdf_joint_index, double *lower, double *upper) {
+  if (!m) return fail(TREX_E_INVALID, "null model");
+  if (k < 0 || k >= m->host.nb - 1) return fail(TREX_E_INVALID, "joint index out of range");
+  int b = m->host.obs_order[k];
+  if (name) *name = m->host.obs_joint_names[k].c_str();
+  if (urdf_joint_index) *urdf_joint_index = m->host.revolute_joint_indices[k];
+  if (lower) *lower = m->host.q_lower[b];
+  if (upper) *upper = m->host.q_upper[b];
+  return TREX_OK;
+}
+
+int trex_model_set_start_angle(TrexModel *m, const char *joint_name, double angle) {
+  if (!m || !joint_name) return fail(TREX_E_INVALID, "null argument");
+  std::string n = trex::rename_v0_name(joint_name);
+  for (int i = 1; i < m->host.nb; i++)
+    if (m->host.joint_names[i] == n) { m->host.q_start[i] = angle; return TREX_OK; }
+  return fail(TREX_E_INVALID, std::string("unknown joint '") + joint_name + "'");
+}
+
+int trex_model_set_start_pose(TrexModel *m, const double xyz[3], const double rpy[3]) {
+  if (!m || !xyz || !rpy) return fail(TREX_E_INVALID, "null argument");
+  m->host.base_start_pos = {xyz[0], xyz[1], xyz[2]};
+  trex::matrix_to_quat(trex::rpy_to_matrix(rpy[0], rpy[1], rpy[2]), m->host.base_start_quat);
+  return TREX_OK;
+}
+
+int trex_model_set_param(TrexModel *m, const char *name, double value) {
+  if (!m || !name) return fail(TREX_E_INVALID, "null argument");
+  double *p = m->host.prm.find(name);
+  if (!p) return fail(TREX_E_INVALID, std::string("unknown parameter '") + name + "'");
+  if (!std::isfinite(value)) return fail(TREX_E_INVALID, "parameter value is not finite");
+  *p = value;
+  return TREX_OK;
+}
+int trex_model_get_param(const TrexModel *m, const char *name, double *value) {
+  if (!m || !name || !value) return fail(TREX_E_INVALID, "null argument");
+  double *p = const_cast<TrexModel *>(m)->host.prm.find(name);
+  if (!p) return fail(TREX_E_INVALID, std::string("unknown parameter '") + name + "'");
+  *value = *p;
+  return TREX_OK;
+}
+
+int trex_model_get_array(const TrexModel *m, const char *name, double *out, int capacity) {
+  if (!m || !name) return fail(TREX_E_INVALID, "null argument");
+  const trex::HostModel &h = m->host;
+  std::vector<double> v;
+  std::string n = name;
+  auto push3 = [&](const std::vector<trex::Vec3> &a) { for (auto &p : a) { v.push_back(p.x); v.push_back(p.y); v.push_back(p.z); } };
+  if (n == "parent") v.assign(h.parent.begin(), h.parent.end());
+  else if (n == "depth") v.assign(h.depth.begin(), h.depth.end());
+  else if (n == "joint_axis") push3(h.joint_axis);
+  else if (n == "joint_pos") push3(h.joint_pos);
+  else if (n == "joint_rot") { for (auto &r : h.joint_rot) v.insert(v.end(), r.m, r.m + 9); }
+  else if (n == "q_lower") v = h.q_lower;
+  else if (n == "q_upper") v = h.q_upper;
+  else if (n == "joint_damping") v = h.joint_damping;
+  else if (n == "mass") v = h.mass;
+  else if (n == "com") push3(h.com);
+  else if (n == "inertia") { for (auto &a : h.inertia) v.insert(v.end(), a.begin(), a.end()); }
+  else if (n == "obs_order") v.assign(h.obs_order.begin(), h.obs_order.end());
+  else if (n == "revolute_joint_indices") v.assign(h.revolute_joint_indices.begin(), h.revolute_joint_indices.end());
+  else if (n == "head_body") v = {(double)h.head_body};
+  else if (n == "head_point") v = {h.head_point.x, h.head_point.y, h.head_point.z};
+  else if (n == "hull_xyz") push3(h.hull_xyz);
+  else if (n == "hull_start") v.assign(h.hull_start.begin(), h.hull_start.end());
+  else if (n == "sphere_center") push3(h.sphere_center);
+  else if (n == "sphere_radius") v = h.sphere_radius;
+  else if (n == "q_start") v = h.q_start;
+  else if (n == "base_start_pos") v = {h.base_start_pos.x, h.base_start_pos.y, h.base_start_pos.z};
+  else if (n == "base_start_quat") v.assign(h.base_start_quat, h.base_start_quat + 4);
+  else return fail(TREX_E_INVALID, "unknown array '" + n + "'");
+  if (out) {
+    if (capacity < (int)v.size()) return fail(TREX_E_INVALID, "capacity too small for '" + n + "'");
+    std::memcpy(out, v.data(), v.size() * sizeof(double));
+  }
+  return (int)v.size();
+}
+
+// ------------------------------------------------------------------ batch
+int trex_batch_create(const TrexModel *model, int num_envs, int device, TrexBatch **out) {
+  if (!model || !out) return fail(TREX_E_INVALID, "trex_batch_create: null argument");
+  *out = nullptr;
+  if (num_envs <= 0) return fail(TREX_E_INVALID, "num_envs must be positive");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0) return fail(TREX_E_HIP, "no HIP device available (the physics step has no CPU fallback)");
+  if (device < 0 || device >= count) return fail(TREX_E_INVALID, "device index out of range");
+  DeviceGuard guard(device);
+  if (!guard.ok) return fail(TREX_E_HIP, "hipSetDevice failed");
+  auto b = std::make_unique<TrexBatch>();
+  b->n = num_envs; b->device = device; b->nb = model->host.nb; b->nj = b->nb - 1;
+  auto alloc = [&](size_t bytes, void **p) -> hipError_t {
+    hipError_t r = hipMalloc(p, bytes);
+    if (r == hipSuccess) { b->allocs.push_back(*p); r = hipMemset(*p, 0, bytes); }
+    return r;
+  };
+  auto cleanup = [&]() { for (void *p : b->allocs) (void)hipFree(p); };
+  TrexDeviceModel dm;
+  fill_device_model(model->host, dm);
+  size_t n = (size_t)num_envs;
+  hipError_t r = hipSuccess;
+  auto A = [&](size_t bytes, void **p) { if (r == hipSuccess) r = alloc(bytes, p); };
+  A(sizeof(TrexDeviceModel), (void **)&b->dmodel);
+  A(n * 16 * sizeof(float), (void **)&b->arr.base);
+  A(n * TREX_TL * sizeof(float), (void **)&b->arr.q);
+  A(n * TREX_TL * sizeof(float), (void **)&b->arr.qd);
+  A(n * TREX_TL * sizeof(float), (void **)&b->arr.tau);
+  A(n * TREX_TL * sizeof(float), (void **)&b->arr.mass_scale);
+  A(n * sizeof(float), (void **)&b->arr.friction);
+  A(n, (void **)&b->arr.motors_on);
+  A(n * sizeof(int32_t), (void **)&b->arr.contact_count);
+  A(n * sizeof(float), (void **)&b->arr.normal_impulse);
+  size_t nv = model->host.hull_xyz.size();
+  A((nv ? nv : 1) * sizeof(float4), (void **)&b->arr.hull);
+  if (r != hipSuccess) { cleanup(); return hip_fail(r, "hipMalloc"); }
+  std::vector<float4> hull(nv ? nv : 1);
+  for (size_t i = 0; i < nv; i++) hull[i] = make_float4((float)model->host.hull_xyz[i].x, (float)model->host.hull_xyz[i].y, (float)model->host.hull_xyz[i].z, 0.f);
+  r = hipMemcpy(b->dmodel, &dm, sizeof dm, hipMemcpyHostToDevice);
+  if (r == hipSuccess) r = hipMemcpy(b->arr.hull, hull.data(), hull.size() * sizeof(float4), hipMemcpyHostToDevice);
+  if (r == hipSuccess) r = trex_launch_fill(b->arr.mass_scale, 1.0f, num_envs * TREX_TL, nullptr);
+  if (r == hipSuccess) r = trex_launch_fill(b->arr.friction, (float)model->host.prm.friction, num_envs, nullptr);
+  if (r == hipSuccess) r = hipDeviceSynchronize();
+  if (r != hipSuccess) { cleanup(); return hip_fail(r, "batch initialisation"); }
+  *out = b.release();
+  return TREX_OK;
+}
+
+void trex_batch_destroy(TrexBatch *b) {
+  if (!b) return;
+  DeviceGuard guard(b->device);
+  (void)hipDeviceSynchronize();
+  for (void *p : b->allocs) (void)hipFree(p);
+  delete b;
+}
+
+int trex_batch_num_envs(const TrexBatch *b) { return b ? b->n : fail(TREX_E_INVALID, "null batch"); }
+
+int trex_batch_set_reward_weights(TrexBatch *b, float distance, float energy, float drift) {
+  if (check_batch(b)) return TREX_E_INVALID;
+  b->wd = distance; b->we = energy; b->wk = drift;
+  return TREX_OK;
+}
+
+int trex_batch_reset(TrexBatch *b, const uint8_t *mask_dev, float *obs_out_dev, void *stream) {
+  if (check_batch(b)) return TREX_E_INVALID;
+  DeviceGuard guard(b->device);
+  HIP_TRY(trex_launch_reset(b->dmodel, b->arr, b->n, mask_dev, obs_out_dev, b->wd, b->we, b->wk, nullptr, (hipStream_t)stream));
+  return TREX_OK;
+}
+
+int trex_batch_step(TrexBatch *b, const float *actions_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev,
+                    float *penalties_dev, void *stream) {
+  if (check_batch(b)) return TREX_E_INVALID;
+  if (!actions_dev) return fail(TREX_E_INVALID, "trex_batch_step: actions is null");
+  DeviceGuard guard(b->device);
+  HIP_TRY(trex_launch_step(b->dmodel, b->arr, b->n, actions_dev, obs_dev, reward_dev, done_dev, penalties_dev, b->wd,
+                           b->we, b->wk, nullptr, (hipStream_t)stream));
+  return TREX_OK;
+}
+
+int trex_batch_debug_step(TrexBatch *b, const float *actions_dev, float *obs_dev, float *debug_dev, void *stream) {
+  if (check_batch(b)) return TREX_E_INVALID;
+  if (!actions_dev || !debug_dev) return fail(TREX_E_INVALID, "trex_batch_debug_step: null argument");
+  DeviceGuard guard(b->device);
+  HIP_TRY(trex_launch_step(b->dmodel, b->arr, b->n, actions_dev, obs_dev, nullptr, nullptr, nullptr, b->wd, b->we, b->wk,
+                           debug_dev, (hipStream_t)stream));
+  return TREX_OK;
+}
+
+int trex_batch_get_state(TrexBatch *b, float *state_dev, void *stream) {
+  if (check_batch(b)) return TREX_E_INVALID;
+  if (!state_dev) return fail(TREX_E_INVALID, "state is null");
+  DeviceGuard guard(b->device);
+  HIP_TRY(trex_launch_pack_state(b->dmodel, b->arr, b->n, state_dev, 1, (hipStream_t)stream));
+  return TREX_OK;
+}
+int trex_batch_set_state(TrexBatch *b, const float *state_dev, void *stream) {
+  if (check_batch(b)) return TREX_E_INVALID;
+  if (!state_dev) return fail(TREX_E_INVALID, "state is null");
+  DeviceGuard guard(b->device);
+  HIP_TRY(trex_launch_pack_state(b->dmodel, b->arr, b->n, const_cast<float *>(state_dev), 0, (hipStream_t)stream));
+  HIP_TRY(trex_launch_fill(b->arr.tau, 0.0f, b->n * TREX_TL, (hipStream_t)stream));
+  return TREX_OK;
+}
+int trex_batch_set_motors_enabled(TrexBatch *b, int enabled, void *stream) {
+  if (check_batch(b)) return TREX_E_INVALID;
+  DeviceGuard guard(b->device);
+  HIP_TRY(trex_launch_fill_u8(b->arr.motors_on, enabled ? 1 : 0, b->n, (hipStream_t)stream));
+  return TREX_OK;
+}
+
+int trex_batch_head_position(TrexBatch *b, float *out_dev, void *stream) {
+  if (check_batch(b)) return TREX_E_INVALID;
+  if (!out_dev) return fail(TREX_E_INVALID, "out is null");
+  DeviceGuard guard(b->device);
+  HIP_TRY(trex_launch_head(b->dmodel, b->arr, b->n, out_dev, (hipStream_t)stream));
+  return TREX_OK;
+}
+
+int trex_batch_set_domain(TrexBatch *b, const float *mass_scale_dev, const float *friction_dev, void *stream) {
+  if (check_batch(b)) return TREX_E_INVALID;
+  DeviceGuard guard(b->device);
+  if (mass_scale_dev) HIP_TRY(trex_launch_copy_mass_scale(mass_scale_dev, b->arr.mass_scale, b->n, b->nb, (hipStream_t)stream));
+  if (friction_dev) HIP_TRY(hipMemcpyAsync(b->arr.friction, friction_dev, b->n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return TREX_OK;
+}
+
+int trex_batch_contact_stats(TrexBatch *b, int32_t *count_dev, float *normal_impulse_dev, void *stream) {
+  if (check_batch(b)) return TREX_E_INVALID;
+  DeviceGuard guard(b->device);
+  if (count_dev) HIP_TRY(hipMemcpyAsync(count_dev, b->arr.contact_count, b->n * sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (normal_impulse_dev) HIP_TRY(hipMemcpyAsync(normal_impulse_dev, b->arr.normal_impulse, b->n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return TREX_OK;
+}
+
+int trex_batch_launch_info(const TrexBatch *b, int *grid, int *block, int *lds_bytes, int *alg_bytes_per_env_step) {
+  if (!b) return fail(TREX_E_INVALID, "null batch");
+  if (grid) *grid = (b->n + 1) / 2;
+  if (block) *block = 64;
+  if (lds_bytes) *lds_bytes = trex_step_lds_bytes();
+  // state in + out (13 + 2J floats each), action in (J), obs out (3J), reward (4 B), done (padded 4 B): SURVEY 8d
+  if (alg_bytes_per_env_step) *alg_bytes_per_env_step = 4 * (2 * (13 + 2 * b->nj) + b->nj + 3 * b->nj + 1 + 1);
+  return TREX_OK;
+}
+
+int trex_batch_time_steps(TrexBatch *b, const float *actions_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev,
+                          int steps, void *stream, float *avg_ms_out) {
+  if (check_batch(b)) return TREX_E_INVALID;
+  if (!actions_dev || !avg_ms_out || steps <= 0) return fail(TREX_E_INVALID, "trex_batch_time_steps: bad argument");
+  DeviceGuard guard(b->device);
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipEventRecord(e0, s));
+  for (int i = 0; i < steps; i++)
+    HIP_TRY(trex_launch_step(b->dmodel, b->arr, b->n, actions_dev, obs_dev, reward_dev, done_dev, nullptr, b->wd, b->we,
+                             b->wk, nullptr, s));
+  HIP_TRY(hipEventRecord(e1, s));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_ms_out = ms / steps;
+  return TREX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,44 @@
+// Device-side layout of the compiled model and of the per-env state (shared by host and kernels).
+#pragma once
+#include <stdint.h>
+
+#define TREX_TL 32        /* lanes per env team = half a wavefront */
+#define TREX_MAXD 6       /* tree depth supported */
+#define TREX_MAXCH 4      /* moving children per body */
+#define TREX_MAXC 16      /* contact points kept per env */
+
+enum TrexParam {
+  TP_DT, TP_SUBSTEPS, TP_ITERATIONS, TP_GRAVITY, TP_MOTOR_KP, TP_MOTOR_KD, TP_MOTOR_MAX_FORCE,
+  TP_FLOOR_Z, TP_FRICTION, TP_ERP, TP_CONTACT_ERP, TP_CONTACT_MARGIN, TP_LINK_DAMPING,
+  TP_MAX_COORD_VEL, TP_MAX_CONTACTS, TP_COUNT
+};
+
+/* Model constants, one copy in HBM (about 5 KB + hull vertices), L2-resident for every wave.
+ * Per-body arrays are [component][lane] so that lane b of a team reads body b: coalesced 128 B. */
+struct TrexDeviceModel {
+  int nb, maxdepth, head_body, nv;
+  float prm[16];
+  float head_point[4];
+  float base_pos0[4], base_quat0[4];
+  int parent[TREX_TL], depth[TREX_TL];
+  int obs_slot[TREX_TL];              /* body -> index in the sorted-joint observation order, -1 for base */
+  int anc[TREX_MAXD][TREX_TL];        /* anc[d-1][b] = ancestor of body b at depth d (b itself at its own depth), -1 beyond */
+  int child[TREX_MAXCH][TREX_TL];     /* moving children of body b, -1 = none */
+  unsigned desc_mask[TREX_TL];        /* per DOF LANE: bit b set if body b's chain contains this dof (base dof lanes: all bodies) */
+  int hull_start[TREX_TL + 1];
+  float axis[3][TREX_TL], jpos[3][TREX_TL], jrot[9][TREX_TL], com[3][TREX_TL], inertia[6][TREX_TL];
+  float mass[TREX_TL], lower[TREX_TL], upper[TREX_TL], damp[TREX_TL], q_start[TREX_TL];
+  float sphere[4][TREX_TL];           /* bounding sphere of the body's hull vertices: cx cy cz r */
+};
+
+/* Per-env state in HBM. One row per env, padded so that a 32-lane team reads whole 128-B segments:
+ *   base  [N][16]  pos(3) quat xyzw(4) v(3) w(3) pad(3)
+ *   q, qd, tau, mass_scale  [N][32]  indexed by BODY lane (lane 0 unused)
+ *   friction [N], motors_on [N] (u8), contact stats [N] */
+struct TrexBatchArrays {
+  float *base, *q, *qd, *tau, *mass_scale, *friction;
+  uint8_t *motors_on;
+  int32_t *contact_count;
+  float *normal_impulse;
+  float4 *hull;  /* [nv] body-frame vertices, w unused */
+};

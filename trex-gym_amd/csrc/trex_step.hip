@@ -1,0 +1,1058 @@
+// K1/K2: fused batched physics step for the T-rex env on gfx950 (MI355X, CDNA4).
+//
+// Replaces, per env and per launch, what TrexBulletEnv.step() (trex_env.py:128-154) asks of pybullet
+// and the robot adapter: clip action -> substeps x [position-motor rows (trex_robot.py:397-422) +
+// stepSimulation (trex_env.py:150)] -> observations (trex_robot.py:359-365) + reward
+// (trex_env.py:186-196); with RESET: TrexBulletEnv.reset() (trex_env.py:98-122).
+//
+// Mapping to the hardware
+//   * one 64-lane wavefront = one workgroup = TWO envs, one per 32-lane half ("team"): the tree has
+//     26 bodies and 25 + 6 = 31 degrees of freedom, so a team's lanes are (a) the bodies 0..25 for the
+//     tree sweeps and (b) the dofs for the constraint solve: lanes 1..25 = joint of that body,
+//     lanes 26..31 = base angular xyz / linear xyz.  No inter-wave synchronisation exists.
+//   * every spatial quantity of an env lives in ONE frame (world axes, origin at the base frame
+//     origin), so parent->child sweeps need no frame transforms: base-to-tip passes move 6..12
+//     registers per level with wavefront shuffles (ds_bpermute within the half), the tip-to-base
+//     articulated-inertia pass stages 27 floats per body through LDS.
+//   * M^-1 is never formed by repeated sweeps: the ABA factorisation M^-1 = A^T B A is kept
+//     DISTRIBUTED (lane j holds column j of A: <= 6 ancestor entries + 6 base entries), which makes
+//     every constraint row's response vector a handful of FMAs.
+//   * projected Gauss-Seidel runs on the velocity level with dv spread over the dof lanes; joint
+//     rows (limits, motors) have unit Jacobians, so only contact rows need a cross-lane reduction.
+//   * HBM traffic per env-step is the state row in/out + action in + obs/reward out (912 B); the
+//     kernel is latency/VALU bound, not bandwidth bound.
+//
+// The arithmetic is the one restated by oracle/trex_oracle.c; tests/ compare the two.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_model.h"
+
+#define TL TREX_TL
+#define MAXD TREX_MAXD
+#define MAXCH TREX_MAXCH
+#define MAXC TREX_MAXC
+
+namespace {
+
+// ---------------------------------------------------------------- team (32-lane) primitives
+__device__ __forceinline__ float tshfl(float v, int src) { return __shfl(v, src, TL); }
+__device__ __forceinline__ int tshfl(int v, int src) { return __shfl(v, src, TL); }
+__device__ __forceinline__ float tsum(float v) {
+#pragma unroll
+  for (int m = TL / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, TL);
+  return v;
+}
+__device__ __forceinline__ unsigned tballot(bool p) {
+  unsigned long long b = __ballot(p);
+  return (unsigned)(b >> (threadIdx.x & 32));
+}
+__device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
+
+__device__ __forceinline__ void cross3(const float *a, const float *b, float *o) {
+  float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+__device__ __forceinline__ float dot3(const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ float dot6(const float *a, const float *b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+}
+__device__ __forceinline__ void matvec3(const float *m, const float *v, float *o) {
+  float x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2];
+  float y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2];
+  float z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+__device__ __forceinline__ void matmul3(const float *a, const float *b, float *o) {
+  float t[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) t[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+#pragma unroll
+  for (int i = 0; i < 9; i++) o[i] = t[i];
+}
+__device__ __forceinline__ void quat_to_mat(const float *q, float *m) {
+  float x = q[0], y = q[1], z = q[2], w = q[3];
+  m[0] = 1 - 2 * (y * y + z * z); m[1] = 2 * (x * y - z * w); m[2] = 2 * (x * z + y * w);
+  m[3] = 2 * (x * y + z * w); m[4] = 1 - 2 * (x * x + z * z); m[5] = 2 * (y * z - x * w);
+  m[6] = 2 * (x * z - y * w); m[7] = 2 * (y * z + x * w); m[8] = 1 - 2 * (x * x + y * y);
+}
+
+// Symmetric 6x6 stored as A(6: xx xy xz yy yz zz) | B(9, row-major upper-right block) | C(6):
+//   M = [[A, B], [B^T, C]]
+struct Sym6 { float A[6], B[9], C[6]; };
+
+__device__ __forceinline__ void sym3_mul(const float *s, const float *v, float *o) {
+  o[0] = s[0] * v[0] + s[1] * v[1] + s[2] * v[2];
+  o[1] = s[1] * v[0] + s[3] * v[1] + s[4] * v[2];
+  o[2] = s[2] * v[0] + s[4] * v[1] + s[5] * v[2];
+}
+__device__ __forceinline__ void sym6_mul(const Sym6 &m, const float *v, float *o) {
+  float a[3], b[3], c[3], d[3];
+  sym3_mul(m.A, v, a);
+  matvec3(m.B, v + 3, b);
+  // B^T w
+  c[0] = m.B[0] * v[0] + m.B[3] * v[1] + m.B[6] * v[2];
+  c[1] = m.B[1] * v[0] + m.B[4] * v[1] + m.B[7] * v[2];
+  c[2] = m.B[2] * v[0] + m.B[5] * v[1] + m.B[8] * v[2];
+  sym3_mul(m.C, v + 3, d);
+#pragma unroll
+  for (int i = 0; i < 3; i++) { o[i] = a[i] + b[i]; o[3 + i] = c[i] + d[i]; }
+}
+// full 6x6 from Sym6 (row-major)
+__device__ __forceinline__ void sym6_full(const Sym6 &m, float *f) {
+  const int sidx[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      f[6 * r + c] = m.A[sidx[r][c]];
+      f[6 * r + 3 + c] = m.B[3 * r + c];
+      f[6 * (3 + r) + c] = m.B[3 * c + r];
+      f[6 * (3 + r) + 3 + c] = m.C[sidx[r][c]];
+    }
+}
+// M -= U U^T * s
+__device__ __forceinline__ void sym6_rank1_sub(Sym6 &m, const float *U, float s) {
+  const int ia[6] = {0, 0, 0, 1, 1, 2}, ib[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    m.A[k] -= U[ia[k]] * U[ib[k]] * s;
+    m.C[k] -= U[3 + ia[k]] * U[3 + ib[k]] * s;
+  }
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) m.B[3 * r + c] -= U[r] * U[3 + c] * s;
+}
+
+// inverse of an SPD 6x6 (Cholesky), result as 21 unique entries of the symmetric inverse, row-major
+// upper triangle: inv[tri(r,c)], r<=c
+__device__ __forceinline__ int tri(int r, int c) { return r * 6 - r * (r - 1) / 2 + (c - r); }
+__device__ __forceinline__ void spd6_inverse(const Sym6 &m, float *inv21) {
+  float a[36], l[36];
+  sym6_full(m, a);
+#pragma unroll
+  for (int i = 0; i < 36; i++) l[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      float s = a[6 * i + j];
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= l[6 * i + k] * l[6 * j + k];
+      if (i == j) l[6 * i + j] = sqrtf(s);
+      else l[6 * i + j] = s / l[6 * j + j];
+    }
+  // Linv (lower triangular), then inv = Linv^T Linv
+  float li[36];
+#pragma unroll
+  for (int i = 0; i < 36; i++) li[i] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 6; c++) {
+#pragma unroll
+    for (int i = c; i < 6; i++) {
+      float s = (i == c) ? 1.f : 0.f;
+#pragma unroll
+      for (int k = c; k < i; k++) s -= l[6 * i + k] * li[6 * k + c];
+      li[6 * i + c] = s / l[6 * i + i];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 6; r++)
+#pragma unroll
+    for (int c = r; c < 6; c++) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = c; k < 6; k++) s += li[6 * k + r] * li[6 * k + c];
+      inv21[tri(r, c)] = s;
+    }
+}
+__device__ __forceinline__ void inv21_mul(const float *inv21, const float *v, float *o) {
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 6; c++) s += inv21[r <= c ? tri(r, c) : tri(c, r)] * v[c];
+    o[r] = s;
+  }
+}
+
+// ---------------------------------------------------------------- LDS layout (per team)
+struct TeamLds {
+  float minv[TL - 7][TL];   // [j-1][dof lane]: column j of M^-1 (j = joint/body 1..25)        3200 B
+  union {
+    float aba[TL][28];      // tip-to-base staging: Ia (21) + pa (6) per body                   3584 B
+    float W[MAXC][3][TL];   // response vectors of the contact rows                             6144 B
+  };
+};
+
+struct KernelArgs {
+  const TrexDeviceModel *model;
+  TrexBatchArrays arr;
+  int n_envs;
+  const float *actions;   // [N, J]
+  float *obs;             // [N, 3J] nullable
+  float *reward;          // [N] nullable
+  uint8_t *done;          // [N] nullable
+  float *penalties;       // [N, 3] nullable
+  const uint8_t *reset_mask;  // RESET only, nullable = all
+  float w_distance, w_energy, w_drift;
+  float *debug;           // diagnostics of env 0's last substep (tests), nullable
+};
+
+}  // namespace
+
+template <bool RESET>
+__global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
+  __shared__ TeamLds lds_all[2];
+  const int lane = threadIdx.x & (TL - 1);
+  const int team = threadIdx.x >> 5;
+  TeamLds &lds = lds_all[team];
+  const TrexDeviceModel *__restrict__ M = args.model;
+  int env = blockIdx.x * 2 + team;
+  const bool env_ok = env < args.n_envs;
+  if (!env_ok) env = args.n_envs - 1;  // duplicate the last env's work, never store it
+
+  const int nb = M->nb, maxdepth = M->maxdepth;
+  const float dt = M->prm[TP_DT];
+  const float inv_dt = 1.0f / dt;
+  const bool is_body = lane < nb;
+  const bool is_joint = lane >= 1 && lane < nb;
+  const int bdof = lane - nb;  // 0..5 on base dof lanes
+  const bool is_base_dof = bdof >= 0 && bdof < 6;
+
+  // ---- model constants of this lane's body
+  const int parent = is_body ? M->parent[lane] : 0;
+  const int psrc = parent < 0 ? 0 : parent;
+  const int depth = is_body ? M->depth[lane] : -1;
+  int anc[MAXD], child[MAXCH];
+#pragma unroll
+  for (int d = 0; d < MAXD; d++) anc[d] = is_body ? M->anc[d][lane] : -1;
+#pragma unroll
+  for (int k = 0; k < MAXCH; k++) child[k] = is_body ? M->child[k][lane] : -1;
+  const unsigned desc_mask = M->desc_mask[lane];
+  float axis[3], jpos[3], jrot[9], comb[3], inb[6];
+#pragma unroll
+  for (int c = 0; c < 3; c++) { axis[c] = M->axis[c][lane]; jpos[c] = M->jpos[c][lane]; comb[c] = M->com[c][lane]; }
+#pragma unroll
+  for (int c = 0; c < 9; c++) jrot[c] = M->jrot[c][lane];
+#pragma unroll
+  for (int c = 0; c < 6; c++) inb[c] = M->inertia[c][lane];
+  const float q_lo = M->lower[lane], q_hi = M->upper[lane], jdamp = M->damp[lane];
+  const int hull_v0 = M->hull_start[lane < nb ? lane : nb], hull_v1 = M->hull_start[lane < nb ? lane + 1 : nb];
+  float sph[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) sph[c] = M->sphere[c][lane];
+  const int obs_slot = is_joint ? M->obs_slot[lane] : -1;
+  const int nj = nb - 1;
+
+  // ---- per-env state
+  float pos[3], quat[4], bv[3], bw[3], q, qd, mtau = 0.f;
+  const float mscale = args.arr.mass_scale[env * TL + lane];
+  const float mass = M->mass[lane] * mscale;
+  const float mu = args.arr.friction[env];
+  bool motors_on;
+  bool do_reset = false;
+  if (RESET) do_reset = args.reset_mask ? (args.reset_mask[env] != 0) : true;
+  if (RESET && do_reset) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) { pos[c] = M->base_pos0[c]; bv[c] = 0.f; bw[c] = 0.f; }
+#pragma unroll
+    for (int c = 0; c < 4; c++) quat[c] = M->base_quat0[c];
+    q = M->q_start[lane]; qd = 0.f;
+    motors_on = false;  // remove_joint_control, trex_robot.py:309
+  } else {
+    const float *b = args.arr.base + env * 16;
+#pragma unroll
+    for (int c = 0; c < 3; c++) { pos[c] = b[c]; bv[c] = b[7 + c]; bw[c] = b[10 + c]; }
+#pragma unroll
+    for (int c = 0; c < 4; c++) quat[c] = b[3 + c];
+    q = args.arr.q[env * TL + lane];
+    qd = args.arr.qd[env * TL + lane];
+    mtau = args.arr.tau[env * TL + lane];
+    motors_on = RESET ? (args.arr.motors_on[env] != 0) : true;
+  }
+  float target = 0.f;
+  if (!RESET && is_joint) {
+    float a = args.actions[env * nj + obs_slot];
+    target = fminf(fmaxf(a, q_lo), q_hi);  // np.clip, trex_env.py:147
+  }
+  const int n_sub = RESET ? (do_reset ? 1 : 0) : (int)M->prm[TP_SUBSTEPS];
+  // a team that does not reset still walks through the loop when its wave partner resets
+  const int n_sub_wave = RESET ? (wave_any(do_reset) ? 1 : 0) : n_sub;
+
+  const float grav = M->prm[TP_GRAVITY], kdamp = M->prm[TP_LINK_DAMPING], vmax = M->prm[TP_MAX_COORD_VEL];
+  const float floor_z = M->prm[TP_FLOOR_Z], margin = M->prm[TP_CONTACT_MARGIN];
+  const float erp = M->prm[TP_ERP], cerp = M->prm[TP_CONTACT_ERP];
+  const float kp = M->prm[TP_MOTOR_KP], kd = M->prm[TP_MOTOR_KD], max_imp = M->prm[TP_MOTOR_MAX_FORCE] * dt;
+  const int iters = (int)M->prm[TP_ITERATIONS];
+  int maxc = (int)M->prm[TP_MAX_CONTACTS];
+  if (maxc > MAXC) maxc = MAXC;
+
+  // kinematic quantities of this lane's body
+  float R[9], r[3], S[6];
+  int stat_nc = 0;
+  float stat_imp = 0.f;
+
+  // FK: world rotation R and origin r (relative to the base origin) of every body; joint motion
+  // subspace S = [a; r x a].  (base-to-tip, one level per step, parent data via shuffles)
+  auto forward_kinematics = [&]() {
+    float Rl[9];
+    {
+      // jrot * Rot(axis, q)
+      float c = cosf(q), s = sinf(q), t = 1.f - c, rq[9];
+      rq[0] = t * axis[0] * axis[0] + c;           rq[1] = t * axis[0] * axis[1] - s * axis[2]; rq[2] = t * axis[0] * axis[2] + s * axis[1];
+      rq[3] = t * axis[0] * axis[1] + s * axis[2]; rq[4] = t * axis[1] * axis[1] + c;           rq[5] = t * axis[1] * axis[2] - s * axis[0];
+      rq[6] = t * axis[0] * axis[2] - s * axis[1]; rq[7] = t * axis[1] * axis[2] + s * axis[0]; rq[8] = t * axis[2] * axis[2] + c;
+      matmul3(jrot, rq, Rl);
+    }
+    quat_to_mat(quat, R);
+    r[0] = r[1] = r[2] = 0.f;
+    for (int d = 1; d <= maxdepth; d++) {
+      float pR[9], pr[3];
+#pragma unroll
+      for (int c = 0; c < 9; c++) pR[c] = tshfl(R[c], psrc);
+#pragma unroll
+      for (int c = 0; c < 3; c++) pr[c] = tshfl(r[c], psrc);
+      if (depth == d) {
+        float o[3];
+        matmul3(pR, Rl, R);
+        matvec3(pR, jpos, o);
+#pragma unroll
+        for (int c = 0; c < 3; c++) r[c] = pr[c] + o[c];
+      }
+    }
+    float a[3];
+    matvec3(R, axis, a);
+    S[0] = a[0]; S[1] = a[1]; S[2] = a[2];
+    cross3(r, a, S + 3);
+    if (!is_joint) {
+#pragma unroll
+      for (int c = 0; c < 6; c++) S[c] = 0.f;
+    }
+  };
+
+  // spatial velocity of every body for base twist (w, v) and joint rates rate (per joint lane)
+  auto body_velocities = [&](const float *w, const float *v, float rate, float *vel) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) { vel[c] = w[c]; vel[3 + c] = v[c]; }
+    for (int d = 1; d <= maxdepth; d++) {
+      float pv[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) pv[c] = tshfl(vel[c], psrc);
+      if (depth == d) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) vel[c] = pv[c] + S[c] * rate;
+      }
+    }
+  };
+
+  for (int sub = 0; sub < n_sub_wave; sub++) {
+    const bool live = sub < n_sub;  // this team really advances
+    forward_kinematics();
+    float vel[6];
+    body_velocities(bw, bv, qd, vel);
+
+    // ---- rigid-body spatial inertia about O, bias force, velocity-product acceleration
+    float comw[3], Icw[6];
+    {
+      float c[3];
+      matvec3(R, comb, c);
+#pragma unroll
+      for (int k = 0; k < 3; k++) comw[k] = r[k] + c[k];
+      // Ic_world = R Ib R^T (symmetric)
+      float t[9];
+      const float Ib[9] = {inb[0], inb[1], inb[2], inb[1], inb[3], inb[4], inb[2], inb[4], inb[5]};
+      matmul3(R, Ib, t);
+      const int ia[6] = {0, 0, 0, 1, 1, 2}, ib[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+      for (int k = 0; k < 6; k++)
+        Icw[k] = mscale * (t[3 * ia[k]] * R[3 * ib[k]] + t[3 * ia[k] + 1] * R[3 * ib[k] + 1] + t[3 * ia[k] + 2] * R[3 * ib[k] + 2]);
+    }
+    Sym6 IA;
+    {
+      const float cc = dot3(comw, comw);
+      IA.A[0] = Icw[0] + mass * (cc - comw[0] * comw[0]);
+      IA.A[1] = Icw[1] - mass * comw[0] * comw[1];
+      IA.A[2] = Icw[2] - mass * comw[0] * comw[2];
+      IA.A[3] = Icw[3] + mass * (cc - comw[1] * comw[1]);
+      IA.A[4] = Icw[4] - mass * comw[1] * comw[2];
+      IA.A[5] = Icw[5] + mass * (cc - comw[2] * comw[2]);
+      // B = m * [c]x
+      IA.B[0] = 0.f;              IA.B[1] = -mass * comw[2];  IA.B[2] = mass * comw[1];
+      IA.B[3] = mass * comw[2];   IA.B[4] = 0.f;              IA.B[5] = -mass * comw[0];
+      IA.B[6] = -mass * comw[1];  IA.B[7] = mass * comw[0];   IA.B[8] = 0.f;
+      IA.C[0] = mass; IA.C[1] = 0.f; IA.C[2] = 0.f; IA.C[3] = mass; IA.C[4] = 0.f; IA.C[5] = mass;
+    }
+    if (!is_body) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) { IA.A[k] = (k == 0 || k == 3 || k == 5) ? 1.f : 0.f; IA.C[k] = IA.A[k]; }
+#pragma unroll
+      for (int k = 0; k < 9; k++) IA.B[k] = 0.f;
+    }
+    float pA[6], cv[6];
+    {
+      float h[6];
+      sym6_mul(IA, vel, h);
+      // v x* h
+      float a[3], b[3], c[3];
+      cross3(vel, h, a); cross3(vel + 3, h + 3, b); cross3(vel, h + 3, c);
+#pragma unroll
+      for (int k = 0; k < 3; k++) { pA[k] = a[k] + b[k]; pA[3 + k] = c[k]; }
+      float f[3] = {0.f, 0.f, -mass * grav}, n[3] = {0.f, 0.f, 0.f};
+      if (kdamp > 0.f) {
+        float vc[3], wxc[3], Iw[3];
+        cross3(vel, comw, wxc);
+#pragma unroll
+        for (int k = 0; k < 3; k++) vc[k] = vel[3 + k] + wxc[k];
+        const float sv = sqrtf(dot3(vc, vc)), sw = sqrtf(dot3(vel, vel));
+        sym3_mul(Icw, vel, Iw);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          f[k] -= mass * vc[k] * (kdamp + kdamp * sv);
+          n[k] -= Iw[k] * (kdamp + kdamp * sw);
+        }
+      }
+      float cxf[3];
+      cross3(comw, f, cxf);
+#pragma unroll
+      for (int k = 0; k < 3; k++) { pA[k] -= n[k] + cxf[k]; pA[3 + k] -= f[k]; }
+      // c = vel x (S qd)
+      float sq[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) sq[k] = S[k] * qd;
+      float x0[3], x1[3], x2[3];
+      cross3(vel, sq, x0); cross3(vel, sq + 3, x1); cross3(vel + 3, sq, x2);
+#pragma unroll
+      for (int k = 0; k < 3; k++) { cv[k] = x0[k]; cv[3 + k] = x1[k] + x2[k]; }
+      if (!is_body) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) { pA[k] = 0.f; cv[k] = 0.f; }
+      }
+    }
+
+    // ---- ABA pass 2 (tip to base): articulated inertias and bias forces through LDS
+    float U[6], Ud[6], invD = 0.f, u = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { U[k] = 0.f; Ud[k] = 0.f; }
+    const float tau_j = -jdamp * qd;  // explicit joint damping torque
+    for (int d = maxdepth; d >= 1; d--) {
+      if (depth == d) {
+        sym6_mul(IA, S, U);
+        invD = 1.0f / dot6(S, U);
+#pragma unroll
+        for (int k = 0; k < 6; k++) Ud[k] = U[k] * invD;
+        u = tau_j - dot6(S, pA);
+        float Ic[6];
+        sym6_mul(IA, cv, Ic);
+        const float uc = dot6(U, cv);
+        Sym6 Ia = IA;
+        sym6_rank1_sub(Ia, U, invD);
+        float *o = lds.aba[lane];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { o[k] = Ia.A[k]; o[15 + k] = Ia.C[k]; }
+#pragma unroll
+        for (int k = 0; k < 9; k++) o[6 + k] = Ia.B[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) o[21 + k] = pA[k] + Ic[k] + U[k] * (u - uc) * invD;
+      }
+      __syncthreads();
+      if (depth == d - 1) {
+#pragma unroll
+        for (int kc = 0; kc < MAXCH; kc++) {
+          const int ch = child[kc];
+          if (ch >= 0) {
+            const float *o = lds.aba[ch];
+#pragma unroll
+            for (int k = 0; k < 6; k++) { IA.A[k] += o[k]; IA.C[k] += o[15 + k]; pA[k] += o[21 + k]; }
+#pragma unroll
+            for (int k = 0; k < 9; k++) IA.B[k] += o[6 + k];
+          }
+        }
+      }
+      __syncthreads();
+    }
+
+    // ---- floating base: a0 = -(IA_0)^-1 pA_0 ; broadcast the inverse to the whole team
+    float I0inv[21], a0[6];
+    {
+      float inv_l[21];
+      spd6_inverse(IA, inv_l);
+#pragma unroll
+      for (int k = 0; k < 21; k++) I0inv[k] = tshfl(inv_l[k], 0);
+      float p0[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) p0[k] = -tshfl(pA[k], 0);
+      inv21_mul(I0inv, p0, a0);
+    }
+    // ---- ABA pass 3 (base to tip): accelerations
+    float qdd = 0.f;
+    {
+      float acc[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) acc[k] = a0[k];
+      for (int d = 1; d <= maxdepth; d++) {
+        float pa[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) pa[k] = tshfl(acc[k], psrc);
+        if (depth == d) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) pa[k] += cv[k];
+          qdd = (u - dot6(U, pa)) * invD;
+#pragma unroll
+          for (int k = 0; k < 6; k++) acc[k] = pa[k] + S[k] * qdd;
+        }
+      }
+    }
+    // ---- unconstrained velocity update; vg = this dof lane's generalised velocity
+    float nw[3], nv[3];
+    {
+      float wxv[3];
+      cross3(bw, bv, wxv);
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        nw[k] = fminf(fmaxf(bw[k] + a0[k] * dt, -vmax), vmax);
+        nv[k] = fminf(fmaxf(bv[k] + (a0[3 + k] + wxv[k]) * dt, -vmax), vmax);
+      }
+    }
+    float nqd = fminf(fmaxf(qd + qdd * dt, -vmax), vmax);
+    float vg = is_joint ? nqd : 0.f;
+    // dof-lane motion subspace: joint lanes S, base dof lanes unit vectors
+    float Sd[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      Sd[k] = is_joint ? S[k] : ((is_base_dof && bdof == k) ? 1.f : 0.f);
+      if (is_base_dof && bdof == k) vg = (k < 3) ? nw[k] : nv[k - 3];
+    }
+
+    // ---- distributed factorisation M^-1 = A^T B A: this lane's column of A
+    //   Aanc[d-1] = entry at its ancestor of depth d (1 at its own depth), A0 = base block entry,
+    //   Z[d-1]    = Aanc[d-1] / D(ancestor), g = I0inv * A0
+    float Aanc[MAXD], Z[MAXD], A0[6], g[6];
+    {
+      float p[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) p[k] = is_joint ? Ud[k] : 0.f;
+#pragma unroll
+      for (int d = MAXD; d >= 1; d--) {
+        Aanc[d - 1] = 0.f; Z[d - 1] = 0.f;
+        if (d <= maxdepth) {
+          const int a = anc[d - 1] < 0 ? 0 : anc[d - 1];
+          float Sa[6], Uda[6];
+#pragma unroll
+          for (int k = 0; k < 6; k++) { Sa[k] = tshfl(S[k], a); Uda[k] = tshfl(Ud[k], a); }
+          const float invDa = tshfl(invD, a);
+          if (is_joint && depth == d) { Aanc[d - 1] = 1.f; Z[d - 1] = invD; }
+          else if (is_joint && depth > d) {
+            const float ua = -dot6(Sa, p);
+            Aanc[d - 1] = ua; Z[d - 1] = ua * invDa;
+#pragma unroll
+            for (int k = 0; k < 6; k++) p[k] += Uda[k] * ua;
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 6; k++) A0[k] = is_joint ? -p[k] : ((is_base_dof && bdof == k) ? 1.f : 0.f);
+      inv21_mul(I0inv, A0, g);
+    }
+    // response of dof lane to a "row" described by (chain ancestors ca[], z-coefficients zc[], base z0)
+    auto response = [&](const int *ca, const float *zc, const float *z0) -> float {
+      float w = dot6(A0, z0);
+#pragma unroll
+      for (int d = 0; d < MAXD; d++) w += (ca[d] >= 0 && ca[d] == anc[d]) ? Aanc[d] * zc[d] : 0.f;
+      return w;
+    };
+    __syncthreads();  // aba staging is dead; W aliases it
+    // ---- joint columns of M^-1 into LDS; diagonal kept in the joint's own lane
+    float mdiag = 1.f;
+    for (int j = 1; j < nb; j++) {
+      int ca[MAXD];
+      float zc[MAXD], z0[6];
+#pragma unroll
+      for (int d = 0; d < MAXD; d++) { ca[d] = tshfl(anc[d], j); zc[d] = tshfl(Z[d], j); }
+#pragma unroll
+      for (int k = 0; k < 6; k++) z0[k] = tshfl(g[k], j);
+      const float w = response(ca, zc, z0);
+      lds.minv[j - 1][lane] = w;
+      if (lane == j) mdiag = w;
+    }
+
+    // ---- joint rows: limits (unilateral, ERP) and position motors
+    const float inv_mdiag = 1.0f / mdiag;
+    float lim_dir = 0.f, lim_rhs = 0.f, lim_lam = 0.f;
+    if (is_joint) {
+      float pen = 0.f;
+      if (q - q_lo <= 0.f) { pen = q - q_lo; lim_dir = 1.f; }
+      else if (q_hi - q <= 0.f) { pen = q_hi - q; lim_dir = -1.f; }
+      lim_rhs = (-pen * erp * inv_dt - lim_dir * vg) * inv_mdiag;
+    }
+    const unsigned lim_mask = tballot(lim_dir != 0.f);
+    float mot_rhs = 0.f, mot_lam = 0.f;
+    const float mot_hi = (is_joint && motors_on) ? max_imp : 0.f;
+    if (is_joint) {
+      // btMultiBodyJointMotor velocity target: kp*(target-q)/dt + qd + kd*(0-qd), minus current qd
+      const float tv = kp * (target - q) * inv_dt + vg + kd * (0.f - vg);
+      mot_rhs = (tv - vg) * inv_mdiag;
+    }
+
+    // ---- contact generation: hull vertices against z <= floor_z
+    int nc = 0;
+    int cbody = 0;
+    float cx[3] = {0.f, 0.f, 0.f}, cdist = 0.f;
+    {
+      float sc[3];
+      matvec3(R, sph, sc);
+      const bool near = is_body && hull_v1 > hull_v0 && (pos[2] + r[2] + sc[2] - sph[3] - floor_z < margin);
+      unsigned near_mask = tballot(near);
+      unsigned active_mask = 0u;
+      while (wave_any(near_mask != 0u)) {
+        const bool valid = near_mask != 0u;
+        const int b = valid ? (__ffs(near_mask) - 1) : 0;
+        near_mask &= near_mask - 1u;
+        const float Rz0 = tshfl(R[6], b), Rz1 = tshfl(R[7], b), Rz2 = tshfl(R[8], b);
+        const float z0 = pos[2] + tshfl(r[2], b) - floor_z;
+        const int v0 = M->hull_start[b], v1 = M->hull_start[b + 1];
+        bool any = false;
+        for (int v = v0 + lane; v < v1; v += TL) {
+          const float4 h = args.arr.hull[v];
+          any |= (z0 + Rz0 * h.x + Rz1 * h.y + Rz2 * h.z) < margin;
+        }
+        if (valid && tballot(any) != 0u) active_mask |= 1u << b;
+      }
+      const int n_active = __popc(active_mask);
+      int K = n_active > 0 ? maxc / n_active : 0;
+      K = K > 4 ? 4 : (K < 1 ? 1 : K);
+      while (wave_any(active_mask != 0u)) {
+        const bool valid = active_mask != 0u;
+        const int b = valid ? (__ffs(active_mask) - 1) : 0;
+        active_mask &= active_mask - 1u;
+        float Rb[9], rb[3];
+#pragma unroll
+        for (int c = 0; c < 9; c++) Rb[c] = tshfl(R[c], b);
+#pragma unroll
+        for (int c = 0; c < 3; c++) rb[c] = tshfl(r[c], b);
+        const int v0 = M->hull_start[b], v1 = M->hull_start[b + 1];
+        int sel[4] = {-1, -1, -1, -1};
+        float px[4][3], pd[4];
+        int nsel = 0;
+        bool stop = !valid;
+#pragma unroll
+        for (int pass = 0; pass < 4; pass++) {
+          float bs = -3.0e38f;
+          int bi = 0x7fffffff;
+          float ex = 0.f, ey = 0.f, flip = 1.f;
+          if (pass >= 2) { ex = px[1][0] - px[0][0]; ey = px[1][1] - px[0][1]; }
+          if (pass == 3) {
+            const float c3 = ex * (px[2][1] - px[0][1]) - ey * (px[2][0] - px[0][0]);
+            flip = c3 > 0.f ? -1.f : 1.f;
+          }
+          for (int v = v0 + lane; v < v1; v += TL) {
+            const float4 h = args.arr.hull[v];
+            const float hv[3] = {h.x, h.y, h.z};
+            float w[3];
+            matvec3(Rb, hv, w);
+            const float x0 = rb[0] + w[0], x1 = rb[1] + w[1], x2 = rb[2] + w[2];
+            const float dd = pos[2] + x2 - floor_z;
+            if (!(dd < margin)) continue;
+            if (v == sel[0] || v == sel[1] || v == sel[2]) continue;
+            float score;
+            if (pass == 0) score = -dd;
+            else {
+              const float dx = x0 - px[0][0], dy = x1 - px[0][1];
+              if (pass == 1) score = dx * dx + dy * dy;
+              else {
+                const float cr = ex * dy - ey * dx;
+                score = (pass == 2) ? fabsf(cr) : flip * cr;
+              }
+            }
+            if (score > bs) { bs = score; bi = v; }
+          }
+#pragma unroll
+          for (int m = TL / 2; m >= 1; m >>= 1) {
+            const float os = __shfl_xor(bs, m, TL);
+            const int oi = __shfl_xor(bi, m, TL);
+            if (os > bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
+          }
+          if (pass >= K || bi == 0x7fffffff || (pass >= 1 && !(bs > 0.f))) stop = true;
+          if (!stop) {
+            const float4 h = args.arr.hull[bi];
+            const float hv[3] = {h.x, h.y, h.z};
+            float w[3];
+            matvec3(Rb, hv, w);
+            sel[pass] = bi;
+#pragma unroll
+            for (int c = 0; c < 3; c++) px[pass][c] = rb[c] + w[c];
+            pd[pass] = pos[2] + px[pass][2] - floor_z;
+            nsel = pass + 1;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (k < nsel && nc < maxc) {
+            if (lane == nc) { cbody = b; cx[0] = px[k][0]; cx[1] = px[k][1]; cx[2] = px[k][2]; cdist = pd[k]; }
+            nc++;
+          }
+        }
+      }
+    }
+
+    // ---- contact rows: lane c owns point c and walks its body's chain for the three directions
+    //      (normal z, friction x, friction y); everything below is per lane, no reductions.
+    float c_rhs[3] = {0.f, 0.f, 0.f}, c_inv[3] = {0.f, 0.f, 0.f}, c_lam[3] = {0.f, 0.f, 0.f};
+    float c_z0[3][6], c_zc[3][MAXD];
+    int c_anc[MAXD];
+    {
+      const bool has = lane < nc;
+      // updated body velocities (after the unconstrained step) for the row right-hand sides
+      float nvel[6];
+      body_velocities(nw, nv, nqd, nvel);
+      float vb[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) vb[k] = tshfl(nvel[k], cbody);
+      float p[3][6], diag[3] = {0.f, 0.f, 0.f};
+      const float dirs[3][3] = {{0.f, 0.f, 1.f}, {1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}};
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        float xd[3];
+        cross3(cx, dirs[a], xd);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { p[a][k] = -xd[k]; p[a][3 + k] = -dirs[a][k]; }
+      }
+#pragma unroll
+      for (int d = MAXD; d >= 1; d--) {
+        c_anc[d - 1] = -1;
+#pragma unroll
+        for (int a = 0; a < 3; a++) c_zc[a][d - 1] = 0.f;
+        if (d <= maxdepth) {
+          const int ab = tshfl(anc[d - 1], cbody);
+          c_anc[d - 1] = has ? ab : -1;
+          const int src = ab < 0 ? 0 : ab;
+          float Sa[6], Uda[6];
+#pragma unroll
+          for (int k = 0; k < 6; k++) { Sa[k] = tshfl(S[k], src); Uda[k] = tshfl(Ud[k], src); }
+          const float invDa = tshfl(invD, src);
+          if (has && ab >= 0) {
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+              const float ua = -dot6(Sa, p[a]);
+              c_zc[a][d - 1] = ua * invDa;
+              diag[a] += ua * ua * invDa;
+#pragma unroll
+              for (int k = 0; k < 6; k++) p[a][k] += Uda[k] * ua;
+            }
+          }
+        }
+      }
+      float pvel[3], wxx[3];
+      cross3(vb, cx, wxx);
+#pragma unroll
+      for (int k = 0; k < 3; k++) pvel[k] = vb[3 + k] + wxx[k];
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        float rhs0[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) rhs0[k] = -p[a][k];
+        inv21_mul(I0inv, rhs0, c_z0[a]);
+        diag[a] += dot6(rhs0, c_z0[a]);
+        c_inv[a] = has ? 1.0f / diag[a] : 0.f;
+        float tv = 0.f;
+        if (a == 0) tv = (cdist > 0.f) ? -cdist * inv_dt : -cdist * cerp * inv_dt;
+        c_rhs[a] = (tv - dot3(dirs[a], pvel)) * c_inv[a];
+      }
+    }
+    const int ncw = max(nc, __shfl_xor(nc, 32));  // both teams walk the same number of points
+    for (int c = 0; c < ncw; c++) {
+      int ca[MAXD];
+#pragma unroll
+      for (int d = 0; d < MAXD; d++) ca[d] = tshfl(c_anc[d], c);
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        float zc[MAXD], z0[6];
+#pragma unroll
+        for (int d = 0; d < MAXD; d++) zc[d] = tshfl(c_zc[a][d], c);
+#pragma unroll
+        for (int k = 0; k < 6; k++) z0[k] = tshfl(c_z0[a][k], c);
+        lds.W[c][a][lane] = (c < nc) ? response(ca, zc, z0) : 0.f;
+      }
+    }
+    __syncthreads();
+
+    // ---- projected Gauss-Seidel, velocity level. Row order = oracle: limits, motors, contacts.
+    float dv = 0.f;
+    const unsigned lim_wave = lim_mask | (unsigned)__shfl_xor((int)lim_mask, 32);
+    for (int it = 0; it < iters; it++) {
+      if (lim_wave) {
+        for (int j = 1; j < nb; j++) {
+          if (!((lim_wave >> j) & 1u)) continue;
+          float delta = 0.f;
+          if (lane == j && lim_dir != 0.f) {
+            float nl = lim_lam + (lim_rhs - lim_dir * dv * inv_mdiag);
+            nl = fmaxf(nl, 0.f);
+            delta = (nl - lim_lam) * lim_dir;
+            lim_lam = nl;
+          }
+          delta = tshfl(delta, j);
+          dv += delta * lds.minv[j - 1][lane];
+        }
+      }
+      for (int j = 1; j < nb; j++) {
+        float delta = 0.f;
+        if (lane == j) {
+          float nl = mot_lam + (mot_rhs - dv * inv_mdiag);
+          nl = fminf(fmaxf(nl, -mot_hi), mot_hi);
+          delta = nl - mot_lam;
+          mot_lam = nl;
+        }
+        delta = tshfl(delta, j);
+        dv += delta * lds.minv[j - 1][lane];
+      }
+      for (int c = 0; c < ncw; c++) {
+        // Jacobian entries of this dof lane for point c: velocity of the point per unit dof rate
+        float x[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) x[k] = tshfl(cx[k], c);
+        const int b = tshfl(cbody, c);
+        float J[3];
+        {
+          float wx[3];
+          cross3(Sd, x, wx);
+          const bool on = (c < nc) && ((desc_mask >> b) & 1u);
+          // order: normal (z), friction x, friction y
+          J[0] = on ? Sd[5] + wx[2] : 0.f;
+          J[1] = on ? Sd[3] + wx[0] : 0.f;
+          J[2] = on ? Sd[4] + wx[1] : 0.f;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          const float jdv = tsum(J[a] * dv);
+          float delta = 0.f;
+          if (lane == c) {
+            float lo = 0.f, hi = 1.0e30f;
+            if (a > 0) { hi = mu * c_lam[0]; lo = -hi; }
+            float nl = c_lam[a] + (c_rhs[a] - jdv * c_inv[a]);
+            nl = fminf(fmaxf(nl, lo), hi);
+            delta = nl - c_lam[a];
+            c_lam[a] = nl;
+          }
+          delta = tshfl(delta, c);
+          dv += delta * lds.W[c][a][lane];
+        }
+      }
+    }
+    __syncthreads();
+
+    if (args.debug && blockIdx.x == 0 && team == 0) {
+      float *D = args.debug;
+      D[lane] = qdd; D[64 + lane] = vg; D[96 + lane] = dv;
+      if (lane < 6) D[32 + lane] = a0[lane];
+      if (lane == 0) { D[128] = (float)nc; D[129] = (float)lim_mask; }
+      for (int j = 1; j < nb; j++) D[160 + 32 * (j - 1) + lane] = lds.minv[j - 1][lane];
+      if (lane < nc) {
+        float *C = D + 960 + lane * 16;
+        C[0] = (float)cbody; C[1] = cx[0]; C[2] = cx[1]; C[3] = cx[2]; C[4] = cdist;
+#pragma unroll
+        for (int a = 0; a < 3; a++) { C[5 + a] = c_inv[a]; C[8 + a] = c_rhs[a]; C[11 + a] = c_lam[a]; }
+      }
+      for (int c = 0; c < nc; c++)
+        for (int a = 0; a < 3; a++) D[1216 + (c * 3 + a) * 32 + lane] = lds.W[c][a][lane];
+    }
+    __syncthreads();
+
+    // ---- commit velocities, integrate positions (only for a team that is really stepping)
+    if (live) {
+      vg += dv;
+      qd = is_joint ? vg : 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; k++) { bw[k] = tshfl(vg, nb + k); bv[k] = tshfl(vg, nb + 3 + k); }
+      mtau = (is_joint && motors_on) ? mot_lam * inv_dt : 0.f;
+      q += qd * dt;
+#pragma unroll
+      for (int k = 0; k < 3; k++) pos[k] += bv[k] * dt;
+      const float wn = sqrtf(dot3(bw, bw)), th = wn * dt;
+      float dq[4] = {0.f, 0.f, 0.f, 1.f};
+      if (th > 1e-12f) {
+        const float sh = sinf(0.5f * th) / wn;
+        dq[0] = bw[0] * sh; dq[1] = bw[1] * sh; dq[2] = bw[2] * sh; dq[3] = cosf(0.5f * th);
+      }
+      float o[4];
+      o[3] = dq[3] * quat[3] - dq[0] * quat[0] - dq[1] * quat[1] - dq[2] * quat[2];
+      o[0] = dq[3] * quat[0] + dq[0] * quat[3] + dq[1] * quat[2] - dq[2] * quat[1];
+      o[1] = dq[3] * quat[1] - dq[0] * quat[2] + dq[1] * quat[3] + dq[2] * quat[0];
+      o[2] = dq[3] * quat[2] + dq[0] * quat[1] - dq[1] * quat[0] + dq[2] * quat[3];
+      const float qn = 1.0f / sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
+#pragma unroll
+      for (int k = 0; k < 4; k++) quat[k] = o[k] * qn;
+      stat_nc = nc;
+      stat_imp = tsum(lane < nc ? c_lam[0] : 0.f);
+    }
+  }
+
+  // ---- head position (needs FK at the new pose: getLinkState(computeForwardKinematics=1))
+  forward_kinematics();
+  float head[3];
+  {
+    const float hp[3] = {M->head_point[0], M->head_point[1], M->head_point[2]};
+    float o[3];
+    matvec3(R, hp, o);
+#pragma unroll
+    for (int k = 0; k < 3; k++) head[k] = tshfl(pos[k] + r[k] + o[k], M->head_body);
+  }
+  const float power = tsum(is_joint ? fabsf(qd * mtau) : 0.f);
+  const float lift = args.w_distance * (2.5f - head[2]) * (2.5f - head[2]);
+  const float drift = args.w_drift * (head[0] * head[0] + head[1] * head[1]);
+  const float energy = args.w_energy * power;
+
+  if (!env_ok) return;
+  // ---- write back
+  const bool store_state = RESET ? do_reset : true;
+  if (store_state) {
+    float *b = args.arr.base + env * 16;
+    if (lane < 3) { b[lane] = pos[lane]; b[7 + lane] = bv[lane]; b[10 + lane] = bw[lane]; }
+    if (lane < 4) b[3 + lane] = quat[lane];
+    args.arr.q[env * TL + lane] = q;
+    args.arr.qd[env * TL + lane] = qd;
+    args.arr.tau[env * TL + lane] = mtau;
+    if (lane == 0) {
+      args.arr.motors_on[env] = motors_on ? 1 : 0;
+      args.arr.contact_count[env] = stat_nc;
+      args.arr.normal_impulse[env] = stat_imp;
+    }
+  }
+  if (args.obs && is_joint) {
+    float *o = args.obs + (size_t)env * 3 * nj;
+    o[obs_slot] = q; o[nj + obs_slot] = qd; o[2 * nj + obs_slot] = mtau;
+  }
+  if (lane == 0) {
+    if (args.reward) args.reward[env] = -lift - drift - energy;
+    if (args.done) args.done[env] = 0;  // should_terminate() is constant False, trex_env.py:183-184
+    if (args.penalties) {
+      args.penalties[env * 3 + 0] = lift; args.penalties[env * 3 + 1] = drift; args.penalties[env * 3 + 2] = energy;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- small utility kernels
+__global__ void trex_pack_state_kernel(const TrexDeviceModel *M, TrexBatchArrays arr, int n, float *out, int pack) {
+  // pack=1: internal -> [N, 13+2J]; pack=0: [N, 13+2J] -> internal
+  const int env = blockIdx.x * (blockDim.x / TL) + threadIdx.x / TL;
+  const int lane = threadIdx.x & (TL - 1);
+  if (env >= n) return;
+  const int nj = M->nb - 1, width = 13 + 2 * nj;
+  float *row = out + (size_t)env * width;
+  float *b = arr.base + env * 16;
+  if (pack) {
+    if (lane < 13) row[lane] = b[lane];
+    if (lane >= 1 && lane < M->nb) {
+      const int s = M->obs_slot[lane];
+      row[13 + s] = arr.q[env * TL + lane];
+      row[13 + nj + s] = arr.qd[env * TL + lane];
+    }
+  } else {
+    if (lane < 13) b[lane] = row[lane];
+    float qv = 0.f, qdv = 0.f;
+    if (lane >= 1 && lane < M->nb) {
+      const int s = M->obs_slot[lane];
+      qv = row[13 + s]; qdv = row[13 + nj + s];
+    }
+    arr.q[env * TL + lane] = qv;
+    arr.qd[env * TL + lane] = qdv;
+  }
+}
+
+__global__ void trex_head_kernel(KernelArgs args, float *out) {
+  // FK only; one team per env. Reuses nothing from the step kernel to stay simple: serial per lane 0.
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= args.n_envs) return;
+  const TrexDeviceModel *M = args.model;
+  const float *b = args.arr.base + env * 16;
+  float quat[4] = {b[3], b[4], b[5], b[6]};
+  // walk from the head body up to the base collecting the chain, then compose base-to-tip
+  int chain[MAXD + 1], n = 0;
+  for (int i = M->head_body; i > 0; i = M->parent[i]) chain[n++] = i;
+  float R[9], r[3] = {0.f, 0.f, 0.f};
+  quat_to_mat(quat, R);
+  for (int k = n - 1; k >= 0; k--) {
+    const int i = chain[k];
+    float ax[3] = {M->axis[0][i], M->axis[1][i], M->axis[2][i]}, jp[3] = {M->jpos[0][i], M->jpos[1][i], M->jpos[2][i]};
+    float jr[9], rq[9], t[9], o[3];
+    for (int c = 0; c < 9; c++) jr[c] = M->jrot[c][i];
+    const float q = args.arr.q[env * TL + i];
+    const float c = cosf(q), s = sinf(q), tt = 1.f - c;
+    rq[0] = tt * ax[0] * ax[0] + c;         rq[1] = tt * ax[0] * ax[1] - s * ax[2]; rq[2] = tt * ax[0] * ax[2] + s * ax[1];
+    rq[3] = tt * ax[0] * ax[1] + s * ax[2]; rq[4] = tt * ax[1] * ax[1] + c;         rq[5] = tt * ax[1] * ax[2] - s * ax[0];
+    rq[6] = tt * ax[0] * ax[2] - s * ax[1]; rq[7] = tt * ax[1] * ax[2] + s * ax[0]; rq[8] = tt * ax[2] * ax[2] + c;
+    matvec3(R, jp, o);
+    for (int k2 = 0; k2 < 3; k2++) r[k2] += o[k2];
+    matmul3(R, jr, t);
+    matmul3(t, rq, R);
+  }
+  const float hp[3] = {M->head_point[0], M->head_point[1], M->head_point[2]};
+  float o[3];
+  matvec3(R, hp, o);
+  for (int k = 0; k < 3; k++) out[env * 3 + k] = b[k] + r[k] + o[k];
+}
+
+__global__ void trex_fill_kernel(float *p, float v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void trex_fill_u8_kernel(uint8_t *p, uint8_t v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void trex_copy_mass_scale_kernel(const float *src, float *dst, int n, int nb) {
+  // [N, nb] -> [N, 32]
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * TL) return;
+  const int e = i / TL, l = i % TL;
+  dst[i] = l < nb ? src[e * nb + l] : 1.0f;
+}
+
+// ---------------------------------------------------------------- host launchers (called by capi.cpp)
+extern "C" {
+
+hipError_t trex_launch_step(const TrexDeviceModel *model, TrexBatchArrays arr, int n, const float *actions,
+                            float *obs, float *reward, uint8_t *done, float *penalties, float wd, float we,
+                            float wk, float *debug, hipStream_t stream) {
+  KernelArgs a{model, arr, n, actions, obs, reward, done, penalties, nullptr, wd, we, wk, debug};
+  hipLaunchKernelGGL(trex_step_kernel<false>, dim3((n + 1) / 2), dim3(64), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t trex_launch_reset(const TrexDeviceModel *model, TrexBatchArrays arr, int n, const uint8_t *mask,
+                             float *obs, float wd, float we, float wk, float *debug, hipStream_t stream) {
+  KernelArgs a{model, arr, n, nullptr, obs, nullptr, nullptr, nullptr, mask, wd, we, wk, debug};
+  hipLaunchKernelGGL(trex_step_kernel<true>, dim3((n + 1) / 2), dim3(64), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t trex_launch_pack_state(const TrexDeviceModel *model, TrexBatchArrays arr, int n, float *state, int pack,
+                                  hipStream_t stream) {
+  hipLaunchKernelGGL(trex_pack_state_kernel, dim3((n + 7) / 8), dim3(256), 0, stream, model, arr, n, state, pack);
+  return hipGetLastError();
+}
+
+hipError_t trex_launch_head(const TrexDeviceModel *model, TrexBatchArrays arr, int n, float *out, hipStream_t stream) {
+  KernelArgs a{model, arr, n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, nullptr};
+  hipLaunchKernelGGL(trex_head_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a, out);
+  return hipGetLastError();
+}
+
+hipError_t trex_launch_fill(float *p, float v, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(trex_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p, v, n);
+  return hipGetLastError();
+}
+hipError_t trex_launch_fill_u8(uint8_t *p, uint8_t v, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(trex_fill_u8_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p, v, n);
+  return hipGetLastError();
+}
+hipError_t trex_launch_copy_mass_scale(const float *src, float *dst, int n, int nb, hipStream_t stream) {
+  hipLaunchKernelGGL(trex_copy_mass_scale_kernel, dim3((n * TL + 255) / 256), dim3(256), 0, stream, src, dst, n, nb);
+  return hipGetLastError();
+}
+
+int trex_step_lds_bytes(void) { return (int)(2 * sizeof(TeamLds)); }
+
+}  // extern "C"

@@ -1,0 +1,223 @@
+"""ctypes binding of libtrex_hip.so (C-ABI in include/trex_batch.h).
+
+There is NO CPU fallback: if the HIP library is missing, importing this module raises; if no GPU
+is present, creating a batch raises TrexError (model loading is host-only and still works).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtrex_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "trex_gym: %s not found - build it with `python __graft_entry__.py` or "
+        "`make -C trex-gym_amd/csrc` (hipcc --offload-arch=gfx950). The physics step has no CPU fallback."
+        % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+PARAM_NAMES = ["dt", "substeps", "iterations", "gravity", "motor_kp", "motor_kd", "motor_max_force",
+               "floor_z", "friction", "erp", "contact_erp", "contact_margin", "link_damping",
+               "max_coordinate_velocity", "max_contacts"]
+# every symbol include/trex_batch.h declares (tests/test_capi_symbols.py parses the header too)
+SYMBOLS = [
+    "trex_last_error", "trex_model_load", "trex_model_destroy", "trex_model_num_bodies",
+    "trex_model_num_joints", "trex_model_num_urdf_joints", "trex_model_num_hull_vertices",
+    "trex_model_total_mass", "trex_model_joint_info", "trex_model_set_start_angle",
+    "trex_model_set_start_pose", "trex_model_set_param", "trex_model_get_param", "trex_model_get_array",
+    "trex_batch_create", "trex_batch_destroy", "trex_batch_num_envs", "trex_batch_set_reward_weights",
+    "trex_batch_reset", "trex_batch_step", "trex_batch_get_state", "trex_batch_set_state",
+    "trex_batch_set_motors_enabled", "trex_batch_head_position", "trex_batch_set_domain",
+    "trex_batch_contact_stats", "trex_batch_debug_step", "trex_batch_launch_info", "trex_batch_time_steps",
+]
+
+_vp = C.c_void_p
+lib.trex_last_error.restype = C.c_char_p
+lib.trex_model_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(_vp)]
+lib.trex_model_destroy.argtypes = [_vp]
+lib.trex_model_destroy.restype = None
+for _n in ("trex_model_num_bodies", "trex_model_num_joints", "trex_model_num_urdf_joints",
+           "trex_model_num_hull_vertices"):
+    getattr(lib, _n).argtypes = [_vp]
+lib.trex_model_total_mass.argtypes = [_vp, C.c_int]
+lib.trex_model_total_mass.restype = C.c_double
+lib.trex_model_joint_info.argtypes = [_vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int),
+                                      C.POINTER(C.c_double), C.POINTER(C.c_double)]
+lib.trex_model_set_start_angle.argtypes = [_vp, C.c_char_p, C.c_double]
+lib.trex_model_set_start_pose.argtypes = [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+lib.trex_model_set_param.argtypes = [_vp, C.c_char_p, C.c_double]
+lib.trex_model_get_param.argtypes = [_vp, C.c_char_p, C.POINTER(C.c_double)]
+lib.trex_model_get_array.argtypes = [_vp, C.c_char_p, C.POINTER(C.c_double), C.c_int]
+lib.trex_batch_create.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(_vp)]
+lib.trex_batch_destroy.argtypes = [_vp]
+lib.trex_batch_destroy.restype = None
+lib.trex_batch_num_envs.argtypes = [_vp]
+lib.trex_batch_set_reward_weights.argtypes = [_vp, C.c_float, C.c_float, C.c_float]
+lib.trex_batch_reset.argtypes = [_vp, _vp, _vp, _vp]
+lib.trex_batch_step.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp]
+lib.trex_batch_debug_step.argtypes = [_vp, _vp, _vp, _vp, _vp]
+lib.trex_batch_get_state.argtypes = [_vp, _vp, _vp]
+lib.trex_batch_set_state.argtypes = [_vp, _vp, _vp]
+lib.trex_batch_set_motors_enabled.argtypes = [_vp, C.c_int, _vp]
+lib.trex_batch_head_position.argtypes = [_vp, _vp, _vp]
+lib.trex_batch_set_domain.argtypes = [_vp, _vp, _vp, _vp]
+lib.trex_batch_contact_stats.argtypes = [_vp, _vp, _vp, _vp]
+lib.trex_batch_launch_info.argtypes = [_vp] + [C.POINTER(C.c_int)] * 4
+lib.trex_batch_time_steps.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, C.POINTER(C.c_float)]
+
+
+class TrexError(RuntimeError):
+    """Raised where the reference would see pybullet.error / KeyError from the engine boundary."""
+
+    def __init__(self, code, message):
+        super().__init__("%s (code %d)" % (message, code))
+        self.code = code
+
+
+def check(code):
+    if code < 0:
+        raise TrexError(code, lib.trex_last_error().decode())
+    return code
+
+
+def _ptr(t):
+    """torch tensor / None -> void* (device pointer)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def default_urdf_path():
+    return os.path.join(_HERE, "..", "assets", "trex_collide.urdf")
+
+
+class Model:
+    """Compiled model (host side). Replaces loadURDF + joint/dynamics introspection."""
+
+    def __init__(self, urdf_path=None, collisions_dir=None):
+        self.urdf_path = os.path.abspath(urdf_path or default_urdf_path())
+        h = _vp()
+        check(lib.trex_model_load(self.urdf_path.encode(),
+                                  collisions_dir.encode() if collisions_dir else None, C.byref(h)))
+        self.h = h
+        self.num_bodies = lib.trex_model_num_bodies(h)
+        self.num_joints = lib.trex_model_num_joints(h)
+        self.num_urdf_joints = lib.trex_model_num_urdf_joints(h)
+        self.joint_names, self.urdf_joint_indices, lo, hi = [], [], [], []
+        for k in range(self.num_joints):
+            name, idx, l, u = C.c_char_p(), C.c_int(), C.c_double(), C.c_double()
+            check(lib.trex_model_joint_info(h, k, C.byref(name), C.byref(idx), C.byref(l), C.byref(u)))
+            self.joint_names.append(name.value.decode())
+            self.urdf_joint_indices.append(idx.value)
+            lo.append(l.value)
+            hi.append(u.value)
+        self.lower = np.array(lo)
+        self.upper = np.array(hi)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib.trex_model_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def total_mass(self, include_base_link=False):
+        return lib.trex_model_total_mass(self.h, int(include_base_link))
+
+    def set_start_angle(self, joint_name, angle):
+        check(lib.trex_model_set_start_angle(self.h, joint_name.encode(), float(angle)))
+
+    def set_start_pose(self, xyz, rpy):
+        a = (C.c_double * 3)(*xyz)
+        b = (C.c_double * 3)(*rpy)
+        check(lib.trex_model_set_start_pose(self.h, a, b))
+
+    def set_param(self, name, value):
+        check(lib.trex_model_set_param(self.h, name.encode(), float(value)))
+
+    def get_param(self, name):
+        v = C.c_double()
+        check(lib.trex_model_get_param(self.h, name.encode(), C.byref(v)))
+        return v.value
+
+    def array(self, name):
+        n = check(lib.trex_model_get_array(self.h, name.encode(), None, 0))
+        out = np.zeros(n)
+        check(lib.trex_model_get_array(self.h, name.encode(), out.ctypes.data_as(C.POINTER(C.c_double)), n))
+        return out
+
+
+class Batch:
+    """N env copies on one GPU; all tensors are torch CUDA(HIP) tensors owned by the caller."""
+
+    def __init__(self, model, num_envs, device=0):
+        self.model = model
+        self.num_envs = int(num_envs)
+        self.device = int(device)
+        h = _vp()
+        check(lib.trex_batch_create(model.h, self.num_envs, self.device, C.byref(h)))
+        self.h = h
+        self.J = model.num_joints
+        self.state_width = 13 + 2 * self.J
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.trex_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _stream(stream):
+        if stream is None:
+            import torch
+            return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return C.c_void_p(stream)
+
+    def set_reward_weights(self, distance, energy, drift):
+        check(lib.trex_batch_set_reward_weights(self.h, distance, energy, drift))
+
+    def reset(self, obs_out=None, mask=None, stream=None):
+        check(lib.trex_batch_reset(self.h, _ptr(mask), _ptr(obs_out), self._stream(stream)))
+
+    def step(self, actions, obs, reward, done, penalties=None, stream=None):
+        check(lib.trex_batch_step(self.h, _ptr(actions), _ptr(obs), _ptr(reward), _ptr(done), _ptr(penalties),
+                                  self._stream(stream)))
+
+    def debug_step(self, actions, obs, debug, stream=None):
+        check(lib.trex_batch_debug_step(self.h, _ptr(actions), _ptr(obs), _ptr(debug), self._stream(stream)))
+
+    def get_state(self, out, stream=None):
+        check(lib.trex_batch_get_state(self.h, _ptr(out), self._stream(stream)))
+
+    def set_state(self, state, stream=None):
+        check(lib.trex_batch_set_state(self.h, _ptr(state), self._stream(stream)))
+
+    def set_motors_enabled(self, enabled, stream=None):
+        check(lib.trex_batch_set_motors_enabled(self.h, int(enabled), self._stream(stream)))
+
+    def head_position(self, out, stream=None):
+        check(lib.trex_batch_head_position(self.h, _ptr(out), self._stream(stream)))
+
+    def set_domain(self, mass_scale=None, friction=None, stream=None):
+        check(lib.trex_batch_set_domain(self.h, _ptr(mass_scale), _ptr(friction), self._stream(stream)))
+
+    def contact_stats(self, count=None, normal_impulse=None, stream=None):
+        check(lib.trex_batch_contact_stats(self.h, _ptr(count), _ptr(normal_impulse), self._stream(stream)))
+
+    def launch_info(self):
+        g, b, l, a = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        check(lib.trex_batch_launch_info(self.h, C.byref(g), C.byref(b), C.byref(l), C.byref(a)))
+        return dict(grid=g.value, block=b.value, lds_bytes=l.value, alg_bytes_per_env_step=a.value)
+
+    def time_steps(self, actions, obs, reward, done, steps, stream=None):
+        ms = C.c_float()
+        check(lib.trex_batch_time_steps(self.h, _ptr(actions), _ptr(obs), _ptr(reward), _ptr(done), int(steps),
+                                        self._stream(stream), C.byref(ms)))
+        return ms.value
