@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/sec of the batched T-rex physics step (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs-per-gpu E]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one TrexBulletEnv.step() of every env: ONE launch of the fused HIP kernel
+(5 substeps x 60 solver iterations, trex_env.py:71-73). Workload at N=1 = BASELINE config 2:
+4096 envs, trex.urdf, uniform random actions in the joint limits, inputs resident in HBM.
+For N>1 every rank owns 4096 envs (weak scaling, BASELINE config 4) and each step ends with the
+RCCL all-gather of the observation rows (the path's only collective).
+
+The JSON line carries `roofline` (algorithmic 912 B/env-step over the kernel's hipEvent-timed
+duration vs the 8 TB/s HBM peak; the kernel is latency/VALU bound so the fraction is tiny - see
+DESIGN.md) and, at N=1, `cpu_baseline`: the f64 CPU oracle (a port; pybullet is absent) timed on
+the host cores on the same kind of workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "trex-gym_amd"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+EPISODE_STEPS = 1000   # harness time limit (the reference never terminates, trex_env.py:183-184)
+
+
+def _cpu_worker(args):
+    """One host core: reset + random-action steps of one env with the f64 oracle for ~budget s."""
+    seed, budget = args
+    import numpy as np
+    from oracle import oracle as O, trex_model as tm
+    m = tm.compile_model(O.default_asset_urdf())
+    orc = O.Oracle(m)
+    lo, hi = m["q_lower"][m["obs_order"]], m["q_upper"][m["obs_order"]]
+    rng = np.random.default_rng(seed)
+    s = orc.new_state()
+    orc.reset(s)
+    for _ in range(20):
+        orc.step(s, rng.uniform(lo, hi))
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget:
+        for _ in range(50):
+            orc.step(s, rng.uniform(lo, hi))
+        n += 50
+        if n % EPISODE_STEPS == 0:
+            orc.reset(s)
+    return n, time.perf_counter() - t0
+
+
+def cpu_baseline(budget_s=12.0):
+    import multiprocessing as mp
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(i, budget_s) for i in range(cores)])
+    total = sum(n for n, _ in res)
+    wall = max(t for _, t in res)
+    try:
+        import pybullet  # noqa: F401
+        pb = "importable (not used: the build's generated URDF cross-check is a later row)"
+    except Exception:  # noqa: BLE001
+        pb = "unavailable on this host"
+    return {"value": total / wall, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "f64 C oracle (oracle/trex_oracle.c), %d processes x 1 env, reset + uniform random "
+                      "actions for %.0f s each (%d env-steps total)" % (cores, budget_s, total),
+            "pybullet": pb}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()  # before the GPU is initialised (spawned workers never touch HIP)
+
+    import torch
+    import torch.distributed as dist
+    from trex_gym import sharding
+    from trex_gym.vec_env import TrexVecEnv
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n_global = args.envs_per_gpu * world
+    env = TrexVecEnv(n_global, device=dev, rank=rank, world_size=world)
+    n_local = env.num_envs
+    lo, hi = env.model.lower, env.model.upper
+    ids = torch.arange(env.env_lo, env.env_hi, device=dev)
+    pool = torch.stack([sharding.synthetic_actions(ids, t, lo, hi, seed=0, device=dev) for t in range(16)])
+
+    def run(n_steps, t_base):
+        for t in range(n_steps):
+            env.step_tensor(pool[(t_base + t) % 16])
+            if world > 1:
+                env.all_gather_obs()
+            if (t_base + t + 1) % EPISODE_STEPS == 0:
+                env.reset_tensor()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    env.reset_tensor()
+    run(args.warmup, 0)
+    fence()
+    t0 = time.perf_counter()
+    run(args.steps, args.warmup)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+
+    # dominant kernel, hipEvent-timed on the stream it runs on (torch's current stream is passed down)
+    kernel_ms = env.batch.time_steps(pool[0], env.obs, env.rew, env.done, min(args.steps, 50))
+    finite = bool(torch.isfinite(env.obs).all().item())
+    info = env.batch.launch_info()
+    if rank == 0:
+        alg = info["alg_bytes_per_env_step"] * n_local  # bytes per launch
+        achieved = alg / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "env-steps/sec (whole node), trex.urdf 4096 envs per MI355X",
+            "value": n_global * args.steps / dt,
+            "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "%d envs per GPU x %d GPU(s), trex.urdf (26 bodies, 31 dof, 2181 hull "
+                                   "vertices), uniform random actions keyed by global env id, 5 substeps x 60 "
+                                   "PGS iterations per step, episode limit %d steps%s"
+                                   % (args.envs_per_gpu, world, EPISODE_STEPS,
+                                      ", obs all-gather over RCCL each step" if world > 1 else ""),
+                       "envs_global": n_global, "parallelism": "env-sharded dp%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "trex_step_kernel<false>", "kernel_ms": kernel_ms,
+                         "alg_bytes_per_launch": alg,
+                         "note": "latency/VALU-bound by construction (serial PGS); HBM fraction reported as "
+                                 "BASELINE asks, see DESIGN.md for the instruction-issue roofline"},
+            "outputs_finite": finite,
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,359 @@
+"""GPU parity tests proper (run with -m gpu on an MI355X): the HIP path, called through the C-ABI
+(trex_gym._capi -> libtrex_hip.so), against the f64 CPU oracle on the same inputs, against the
+committed golden rollouts, and - at BASELINE's full 4096 envs - through size-independent properties.
+
+Stated tolerances (f32 kernel vs f64 oracle; PGS amplifies rounding in contact):
+  one env-step from an identical state: |dq| <= 2e-4 rad, |dqd| <= 1e-2 * max(1, |qd|_inf),
+  motor torque <= 2e-2 * max|tau| (+1 N m), reward <= 2e-3 relative (+1e-3)
+  contact-free trajectories (25 steps): |dq| <= 5e-5, |dqd| <= 5e-4
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ASSET_URDF
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_rollout.npz"))
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from trex_gym import _capi
+    return _capi
+
+
+def make_vec(n, **kw):
+    from trex_gym.vec_env import TrexVecEnv
+    return TrexVecEnv(n, urdf_path=ASSET_URDF, device=DEV, **kw)
+
+
+def assert_step_close(g_obs, o_obs, g_rew=None, o_rew=None, what=""):
+    J = 25
+    assert np.isfinite(g_obs).all(), what
+    np.testing.assert_allclose(g_obs[:J], o_obs[:J], atol=2e-4, rtol=0, err_msg=what + " q")
+    np.testing.assert_allclose(g_obs[J:2 * J], o_obs[J:2 * J], atol=1e-2 * max(1.0, np.abs(o_obs[J:2 * J]).max()),
+                               rtol=0, err_msg=what + " qd")
+    np.testing.assert_allclose(g_obs[2 * J:], o_obs[2 * J:], atol=2e-2 * np.abs(o_obs[2 * J:]).max() + 1.0, rtol=0,
+                               err_msg=what + " tau")
+    if g_rew is not None:
+        assert abs(g_rew - o_rew) <= 2e-3 * abs(o_rew) + 1e-3, (what, g_rew, o_rew)
+
+
+def test_native_library_is_the_one_loaded(capi):
+    assert os.path.exists(capi.LIB_PATH)
+    assert "libtrex_hip.so" in open("/proc/self/maps").read()
+
+
+def test_reset_matches_oracle(oracle64):
+    v = make_vec(5)
+    obs = v.reset()
+    s = oracle64.new_state()
+    want = oracle64.reset(s)
+    for e in range(5):
+        np.testing.assert_allclose(obs[e], want, atol=2e-6)
+    st = v.get_state().cpu().numpy()
+    np.testing.assert_allclose(st[0], oracle64.get_state(s), atol=2e-6)
+    np.testing.assert_allclose(v.head_position().cpu().numpy()[0], oracle64.head_position(s), atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["zero", "crouch", "random"])
+def test_golden_rollout_contact_free_window(name):
+    """Committed oracle vectors, first 20 env-steps (before any contact in all three plans)."""
+    v = make_vec(2)
+    obs = v.reset()
+    np.testing.assert_allclose(obs[0], GOLD[name + "_obs"][0], atol=2e-6)
+    acts = GOLD[name + "_actions"]
+    n = 8 if name != "crouch" else 25   # zero/random actions drive the legs into the ground early
+    for t in range(n):
+        a = np.tile(acts[t], (2, 1)).astype(np.float32)
+        obs, rew, done, info = v.step(a)
+        np.testing.assert_allclose(obs[0, :25], GOLD[name + "_obs"][t + 1][:25], atol=5e-5, err_msg="q step %d" % t)
+        np.testing.assert_allclose(obs[0, 25:50], GOLD[name + "_obs"][t + 1][25:50], atol=5e-4, err_msg="qd step %d" % t)
+        want_r = GOLD[name + "_reward"][t]
+        assert abs(rew[0] - want_r) <= 1e-3 * abs(want_r) + 1e-4
+        assert not done.any() and info[0] == {}
+
+
+@pytest.mark.parametrize("name", ["zero", "crouch", "random"])
+def test_one_step_parity_from_golden_states(name, oracle64):
+    """Every state of the golden rollouts (free fall, impact, rest) -> ONE env-step on GPU and oracle."""
+    states = GOLD[name + "_state"][:-1]
+    acts = GOLD[name + "_actions"]
+    n = len(acts)
+    v = make_vec(n)
+    v.reset()
+    v.set_state(torch.tensor(states, dtype=torch.float32), motors_enabled=True)
+    obs, rew, done, _ = v.step(acts.astype(np.float32))
+    for t in range(n):
+        s = oracle64.new_state()
+        oracle64.set_state(s, states[t].astype(np.float32).astype(np.float64))
+        o, r, p = oracle64.step(s, acts[t].astype(np.float32).astype(np.float64))
+        assert_step_close(obs[t], o, rew[t], r, "%s state %d" % (name, t))
+
+
+def test_one_step_parity_in_contact_and_at_rest(oracle64, model):
+    """States sampled along a 300-step landing (contacts, friction, joint stops under load)."""
+    q0 = model["q_start"][model["obs_order"]]
+    lo, hi = model["q_lower"][model["obs_order"]], model["q_upper"][model["obs_order"]]
+    rng = np.random.default_rng(5)
+    s = oracle64.new_state()
+    oracle64.reset(s)
+    states, acts = [], []
+    for t in range(300):
+        a = np.clip(q0 + 0.15 * rng.normal(size=25), lo, hi)
+        oracle64.step(s, a)
+        if t % 6 == 0:
+            states.append(oracle64.get_state(s).astype(np.float32))
+            acts.append(np.clip(q0 + 0.15 * rng.normal(size=25), lo, hi).astype(np.float32))
+    states, acts = np.array(states), np.array(acts)
+    v = make_vec(len(states))
+    v.reset()
+    v.set_state(torch.tensor(states))
+    obs, rew, _, _ = v.step(acts)
+    cnt = torch.zeros(len(states), dtype=torch.int32, device=DEV)
+    v.batch.contact_stats(cnt, None)
+    n_contact_states = 0
+    for t in range(len(states)):
+        s2 = oracle64.new_state()
+        oracle64.set_state(s2, states[t].astype(np.float64))
+        o, r, p = oracle64.step(s2, acts[t].astype(np.float64))
+        assert_step_close(obs[t], o, rew[t], r, "landing state %d" % t)
+        nco = len(oracle64.contacts(s2)[0])
+        assert cnt[t].item() == nco
+        n_contact_states += nco > 0
+    assert n_contact_states > 20
+
+
+def test_long_rollout_statistics(oracle64, model):
+    """Through contact trajectories decorrelate (chaos), so compare what the physics fixes:
+    rest height, carried weight, contact count (SURVEY 7 'contact chaos')."""
+    q0 = model["q_start"][model["obs_order"]].astype(np.float32)
+    v = make_vec(4)
+    v.reset()
+    a = np.tile(q0, (4, 1))
+    for t in range(400):
+        obs, rew, _, _ = v.step(a)
+    s = oracle64.new_state()
+    oracle64.reset(s)
+    for t in range(400):
+        o, r, _ = oracle64.step(s, q0)
+    st = v.get_state().cpu().numpy()[0]
+    so = oracle64.get_state(s)
+    assert abs(st[2] - so[2]) < 0.02
+    assert np.abs(st[7:13]).max() < 0.1
+    imp = torch.zeros(4, device=DEV)
+    cnt = torch.zeros(4, dtype=torch.int32, device=DEV)
+    v.batch.contact_stats(cnt, imp)
+    w = model["mass"].sum() * 9.81
+    assert abs(imp[0].item() / 0.002 - w) < 0.05 * w
+    assert cnt[0].item() == len(oracle64.contacts(s)[0])
+    assert abs(rew[0] - r) < 0.02 * abs(r) + 0.05
+
+
+def test_joint_limit_rows(oracle64, model):
+    lo = model["q_lower"][model["obs_order"]]
+    st = np.zeros((3, 63), np.float32)
+    st[:, 2] = 50
+    st[:, 6] = 1
+    st[:, 13:38] = lo - 0.05
+    v = make_vec(3)
+    v.reset()
+    v.set_state(torch.tensor(st))
+    a = np.tile(lo, (3, 1)).astype(np.float32)
+    obs, _, _, _ = v.step(a)
+    s = oracle64.new_state()
+    oracle64.set_state(s, st[0].astype(np.float64))
+    o, _, _ = oracle64.step(s, a[0].astype(np.float64))
+    assert_step_close(obs[0], o, what="limits")
+    assert np.all(obs[0, :25] > lo - 0.05)
+
+
+def test_domain_randomisation_matches_oracle(oracle64, model):
+    rng = np.random.default_rng(1)
+    n = 6
+    ms = rng.uniform(0.8, 1.2, (n, 26)).astype(np.float32)
+    mu = rng.uniform(0.5, 1.25, n).astype(np.float32)
+    states = GOLD["crouch_state"][30:30 + n].astype(np.float32)   # around touchdown
+    acts = GOLD["crouch_actions"][:n].astype(np.float32)
+    v = make_vec(n)
+    v.reset()
+    v.set_domain(torch.tensor(ms), torch.tensor(mu))
+    v.set_state(torch.tensor(states))
+    obs, rew, _, _ = v.step(acts)
+    differs = 0
+    for e in range(n):
+        s = oracle64.new_state()
+        oracle64.set_domain(s, ms[e].astype(np.float64), float(mu[e]))
+        oracle64.set_state(s, states[e].astype(np.float64))
+        o, r, _ = oracle64.step(s, acts[e].astype(np.float64))
+        assert_step_close(obs[e], o, rew[e], r, "domain env %d" % e)
+        s0 = oracle64.new_state()
+        oracle64.set_state(s0, states[e].astype(np.float64))
+        o0, _, _ = oracle64.step(s0, acts[e].astype(np.float64))
+        differs += np.abs(o0 - o).max() > 1e-3
+    assert differs >= n - 1   # the randomisation really changes the dynamics
+
+
+def test_action_repeat_and_params(oracle64, model):
+    from oracle import oracle as O
+    orc = O.Oracle(model, params=dict(substeps=10, iterations=20))
+    v = make_vec(2, action_repeat=2, params=dict(iterations=20))
+    obs = v.reset()
+    s = orc.new_state()
+    orc.reset(s)
+    a = GOLD["random_actions"][0].astype(np.float32)
+    obs, rew, _, _ = v.step(np.tile(a, (2, 1)))
+    o, r, _ = orc.step(s, a.astype(np.float64))
+    assert_step_close(obs[0], o, rew[0], r, "action_repeat=2")
+
+
+# ---------------------------------------------------------------- full-size properties (4096 envs)
+N_FULL = 4096
+
+
+@pytest.fixture(scope="module")
+def full(model):
+    v = make_vec(N_FULL)
+    lo = torch.tensor(model["q_lower"][model["obs_order"]], dtype=torch.float32, device=DEV)
+    hi = torch.tensor(model["q_upper"][model["obs_order"]], dtype=torch.float32, device=DEV)
+    return v, lo, hi
+
+
+def test_full_identical_envs_stay_bitwise_identical(full):
+    v, lo, hi = full
+    v.reset_tensor()
+    g = torch.Generator(device=DEV).manual_seed(0)
+    for t in range(40):    # through first contact
+        a = (lo + (hi - lo) * torch.rand(1, 25, device=DEV, generator=g)).expand(N_FULL, 25).contiguous()
+        obs, rew, done = v.step_tensor(a)
+    assert torch.isfinite(obs).all()
+    assert (obs == obs[0:1]).all() and (rew == rew[0]).all()
+    st = v.get_state()
+    assert (st == st[0:1]).all()
+
+
+def test_full_envs_are_independent_and_deterministic(full):
+    """Permuting the action rows permutes the results; repeating the run reproduces them bitwise."""
+    v, lo, hi = full
+    g = torch.Generator(device=DEV).manual_seed(1)
+    acts = lo + (hi - lo) * torch.rand(30, N_FULL, 25, device=DEV, generator=g)
+    perm = torch.randperm(N_FULL, device=DEV, generator=g)
+
+    def run(a_all):
+        v.reset_tensor()
+        for t in range(a_all.shape[0]):
+            obs, rew, _ = v.step_tensor(a_all[t].contiguous())
+        return obs.clone(), rew.clone(), v.get_state()
+    o1, r1, s1 = run(acts)
+    o2, r2, s2 = run(acts)
+    assert (o1 == o2).all() and (r1 == r2).all() and (s1 == s2).all()
+    o3, r3, s3 = run(acts[:, perm])
+    assert (o3 == o1[perm]).all() and (r3 == r1[perm]).all() and (s3 == s1[perm]).all()
+    assert torch.isfinite(o1).all()
+    assert (o1[:, 50:].abs() <= 3.0e5 * (1 + 1e-6)).all()      # motor clamp, trex_robot.py:260
+    assert o1.std(0).max() > 0                                 # envs really differ
+
+
+def test_full_clipping_equals_clipped_actions(full):
+    v, lo, hi = full
+    g = torch.Generator(device=DEV).manual_seed(2)
+    raw = 4.0 * torch.randn(N_FULL, 25, device=DEV, generator=g)
+    v.reset_tensor()
+    o1, r1, _ = v.step_tensor(raw)
+    o1, r1 = o1.clone(), r1.clone()
+    v.reset_tensor()
+    o2, r2, _ = v.step_tensor(torch.minimum(torch.maximum(raw, lo), hi))
+    assert (o1 == o2).all() and (r1 == r2).all()
+
+
+def test_full_masked_reset_and_state_round_trip(full):
+    v, lo, hi = full
+    g = torch.Generator(device=DEV).manual_seed(3)
+    v.reset_tensor()
+    for t in range(5):
+        v.step_tensor(lo + (hi - lo) * torch.rand(N_FULL, 25, device=DEV, generator=g))
+    before = v.get_state()
+    obs_before = v.obs.clone()
+    mask = (torch.rand(N_FULL, device=DEV, generator=g) < 0.3).to(torch.uint8)
+    obs = v.reset_tensor(mask).clone()
+    after = v.get_state()
+    keep = mask == 0
+    assert (after[keep] == before[keep]).all() and (obs[keep] == obs_before[keep]).all()
+    fresh = make_vec(2)
+    f_obs = torch.tensor(fresh.reset(), device=DEV)
+    assert (obs[~keep] == f_obs[0]).all()
+    assert (after[~keep] == fresh.get_state()[0]).all()
+    # set_state(get_state()) is the identity
+    v.set_state(after)
+    assert (v.get_state() == after).all()
+
+
+def test_reward_is_the_reference_formula(full):
+    """r = -w_d (2.5 - z)^2 - w_k (x^2 + y^2) - w_e sum|qd tau| with the head COM (trex_env.py:186-192)."""
+    v, lo, hi = full
+    g = torch.Generator(device=DEV).manual_seed(4)
+    v.reset_tensor()
+    for t in range(35):
+        obs, rew, _ = v.step_tensor(lo + (hi - lo) * torch.rand(N_FULL, 25, device=DEV, generator=g))
+    head = v.head_position().double()
+    power = (obs[:, 25:50].double() * obs[:, 50:].double()).abs().sum(1)
+    want = -1.0 * (2.5 - head[:, 2]) ** 2 - 0.002 * (head[:, 0] ** 2 + head[:, 1] ** 2) - 0.005 * power
+    assert torch.allclose(rew.double(), want, rtol=2e-4, atol=1e-3)
+    assert torch.allclose(v.penalties.double().sum(1), -rew.double(), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("n", [1, 3, 63, 4095])
+def test_ragged_batch_sizes(n):
+    v = make_vec(n)
+    obs = v.reset()
+    ref = make_vec(2).reset()
+    assert obs.shape == (n, 75) and np.array_equal(obs, np.tile(ref[0], (n, 1)))
+    o, r, d, i = v.step(np.zeros((n, 25), np.float32))
+    assert o.shape == (n, 75) and r.shape == (n,) and d.shape == (n,) and len(i) == n
+    assert np.array_equal(o, np.tile(o[0], (n, 1)))
+
+
+def test_time_limit_auto_reset():
+    v = make_vec(4, max_episode_steps=3)
+    first = v.reset().copy()
+    for t in range(3):
+        obs, rew, done, _ = v.step(np.zeros((4, 25), np.float32))
+    assert done.all() and np.array_equal(obs, first)      # VecEnv semantics: obs of the new episode
+    obs, rew, done, _ = v.step(np.zeros((4, 25), np.float32))
+    assert not done.any()
+
+
+def test_error_paths(capi):
+    v = make_vec(2)
+    with pytest.raises(ValueError):
+        v.step_tensor(torch.zeros(2, 24, device=DEV))
+    with pytest.raises(capi.TrexError):
+        make_vec(2, starting_configuration={"no_such_joint": 0.1})
+    with pytest.raises(capi.TrexError):
+        capi.Batch(v.model, 0)
+
+
+def test_single_env_facade_keeps_the_reference_surface(oracle64):
+    from trex_gym import trex_env
+    env = trex_env.TrexBulletEnv(ASSET_URDF)
+    assert env.action_space.shape == (25,) and env.observation_space.shape == (75,)
+    assert env.action_space.dtype == np.float32
+    assert len(env.model._revolute_joint_indices) == 25
+    assert abs(env.model._total_mass - 4834.87) < 0.01        # trex_train.py:123 logs this
+    lo, hi = env.model.get_action_limits()
+    assert np.allclose(env.action_space.low, lo) and np.allclose(env.observation_space.high[25:], 1e12)
+    obs = env.reset()
+    assert isinstance(obs, list) and len(obs) == 75
+    s = oracle64.new_state()
+    np.testing.assert_allclose(obs, oracle64.reset(s), atol=2e-6)
+    o, r, d, info = env.step(np.zeros(50))       # the docstring's 2J-long action: first J entries used
+    assert isinstance(o, list) and isinstance(r, float) and d is False and info == {}
+    oo, ro, _ = oracle64.step(s, np.zeros(25))
+    assert_step_close(np.array(o), oo, r, ro, "facade")
+    assert env.seed(7) == [7]
+    with pytest.raises(ValueError):
+        env.step(np.zeros(3))

@@ -1,0 +1,99 @@
+"""The N>1 path on CPU: world_size-2 gloo processes shard the env ids, generate actions keyed by the
+GLOBAL env id, advance their shard (with the CPU oracle standing in for the GPU kernel - this is a
+test) and all-gather the observation rows. The gathered result must equal the single-process run."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def test_shard_range_partitions():
+    from trex_gym import sharding
+    for n, w in [(4096, 8), (32768, 8), (10, 3), (5, 8), (1, 1)]:
+        spans = [sharding.shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sharding.shard_range(8, 8, 8)
+
+
+def test_synthetic_actions_keyed_by_global_id():
+    from trex_gym import sharding
+    lo, hi = -np.ones(25, np.float32), 2 * np.ones(25, np.float32)
+    full = sharding.synthetic_actions(np.arange(64), 7, lo, hi, seed=3)
+    part = sharding.synthetic_actions(np.arange(16, 48), 7, lo, hi, seed=3)
+    assert torch.equal(full[16:48], part)
+    assert (full >= -1).all() and (full < 2).all()
+    other = sharding.synthetic_actions(np.arange(64), 8, lo, hi, seed=3)
+    assert not torch.equal(full, other)
+    u = (full + 1) / 3
+    assert 0.4 < u.mean() < 0.6 and u.std() > 0.2       # roughly uniform
+    assert len(torch.unique(full)) > 0.99 * full.numel()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rollout(env_ids, steps):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "trex-gym_amd"))
+    from oracle import oracle as O, trex_model as tm
+    from trex_gym import sharding
+    m = tm.compile_model(O.default_asset_urdf())
+    orc = O.Oracle(m)
+    lo, hi = m["q_lower"][m["obs_order"]], m["q_upper"][m["obs_order"]]
+    states = []
+    for _ in env_ids:
+        s = orc.new_state()
+        orc.reset(s)
+        states.append(s)
+    obs = np.zeros((len(env_ids), 75), np.float32)
+    for t in range(steps):
+        a = sharding.synthetic_actions(env_ids, t, lo, hi, seed=0).numpy()
+        for k, s in enumerate(states):
+            obs[k] = orc.step(s, a[k].astype(np.float64))[0]
+    return torch.from_numpy(obs)
+
+
+def _worker(rank, world, port, n_global, steps, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "trex-gym_amd"))
+    from trex_gym import sharding
+    lo, hi = sharding.shard_range(n_global, rank, world)
+    local = _rollout(list(range(lo, hi)), steps)
+    full = sharding.all_gather_rows(local, n_global, world)
+    if rank == 0:
+        ret["gathered"] = full.clone()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_global", [4, 5])
+def test_two_rank_gloo_gather_equals_single_process(n_global):
+    steps = 3
+    want = _rollout(list(range(n_global)), steps)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, n_global, steps, ret), nprocs=2, join=True)
+    got = ret["gathered"]
+    assert got.shape == want.shape
+    assert torch.equal(got, want)
+    assert not torch.equal(want[0], want[1])   # different global ids -> different actions -> rows

@@ -1,0 +1,63 @@
+"""Env-id sharding across the GPUs of one node and the one collective of the path.
+
+Envs are independent (the reference runs a single env, trex_train.py:44), so the batch shards by
+contiguous env-id ranges with no data-path collective. The only exchange is the all-gather of the
+observation rows when a centralised consumer wants the whole batch: `all_gather_rows`
+(torch.distributed.all_gather_into_tensor: RCCL over xGMI with backend "nccl" on ROCm, gloo in the
+CPU tests). Device-agnostic on purpose: nothing here touches HIP.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(num_envs, rank, world_size):
+    """Contiguous [lo, hi) of global env ids owned by `rank`; sizes differ by at most one."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank %d outside world of %d" % (rank, world_size))
+    base, extra = divmod(int(num_envs), int(world_size))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def synthetic_actions(env_ids, step, low, high, seed=0, device="cpu"):
+    """Uniform actions in [low, high) keyed by (seed, GLOBAL env id, step): any sharding of the env
+    ids produces the same rows. Counter-based: a hash of the key, no RNG state."""
+    ids = torch.as_tensor(env_ids, dtype=torch.int64, device=device).reshape(-1, 1)
+    low = torch.as_tensor(low, dtype=torch.float32, device=device).reshape(1, -1)
+    high = torch.as_tensor(high, dtype=torch.float32, device=device).reshape(1, -1)
+    j = torch.arange(low.shape[1], dtype=torch.int64, device=device).reshape(1, -1)
+    x = (ids * 1000003 + int(step)) * 1000033 + j * 7919 + int(seed) * 104729 + 12345
+    # splitmix-style integer mix in 31-bit arithmetic (exact on every backend)
+    m = (1 << 31) - 1
+    x = x & m
+    for mul, sh in ((1103515245, 15), (214013, 13), (69069, 16)):
+        x = (x * mul + 12345) & m
+        x = x ^ (x >> sh)
+    u = (x & ((1 << 24) - 1)).to(torch.float32) / float(1 << 24)
+    return low + (high - low) * u
+
+
+def all_gather_rows(local, global_rows, world_size, group=None, out=None):
+    """Concatenate per-rank row blocks [n_r, C] into [global_rows, C] on every rank. Shards may
+    differ by one row, so blocks are padded to the largest shard for the collective."""
+    if world_size == 1:
+        return local
+    cols = local.shape[1:]
+    per = -(-int(global_rows) // int(world_size))
+    send = local
+    if local.shape[0] != per:
+        send = torch.zeros((per,) + tuple(cols), dtype=local.dtype, device=local.device)
+        send[: local.shape[0]] = local
+    buf = torch.empty((world_size * per,) + tuple(cols), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(buf, send.contiguous(), group=group)
+    if world_size * per == global_rows:
+        if out is not None:
+            out.copy_(buf)
+            return out
+        return buf
+    pieces = []
+    for r in range(world_size):
+        lo, hi = shard_range(global_rows, r, world_size)
+        pieces.append(buf[r * per: r * per + (hi - lo)])
+    return torch.cat(pieces, 0)

@@ -1,0 +1,152 @@
+"""Batched T-rex env on one MI355X: N independent copies of TrexBulletEnv advanced by one HIP kernel
+launch per step (C-ABI: include/trex_batch.h).
+
+Surface = baselines' VecEnv, which is what ppo2.learn drives in the reference (trex_train.py:41-49:
+DummyVecEnv([make_env]) -> VecNormalize): num_envs, observation_space, action_space, reset(),
+step_async(), step_wait(), step(), close(); plus tensor-native variants that keep everything in HBM
+(step_tensor) for an on-device policy.  Episodes never terminate in the reference
+(should_terminate() is constant False, trex_env.py:183-184); a time limit, if any, is the
+harness's: `max_episode_steps` (None = never) auto-resets like a VecEnv does and reports done=True.
+
+Multi-GPU: one process per GPU, env ids sharded by contiguous range (trex_gym.sharding); the only
+exchange is the all-gather of the observation rows (all_gather_obs).
+"""
+import numpy as np
+import torch
+
+from . import _capi, sharding, spaces
+
+REWARD_DEFAULTS = dict(distance_weight=1.0, energy_weight=0.005, drift_weight=0.002)  # trex_env.py:42-44
+
+
+class TrexVecEnv:
+    metadata = {"render.modes": ["human", "rgb_array"], "video.frames_per_second": 50}  # trex_env.py:33-36
+
+    def __init__(self, num_envs, urdf_path=None, collisions_dir=None, device=None, action_repeat=1,
+                 distance_weight=1.0, energy_weight=0.005, drift_weight=0.002,
+                 max_episode_steps=None, starting_configuration=None, params=None,
+                 rank=0, world_size=1, process_group=None):
+        """num_envs is the GLOBAL env count; this process owns sharding.shard_range(num_envs, rank, world_size)."""
+        self.global_num_envs = int(num_envs)
+        self.rank, self.world_size, self.process_group = int(rank), int(world_size), process_group
+        self.env_lo, self.env_hi = sharding.shard_range(self.global_num_envs, self.rank, self.world_size)
+        self.num_envs = self.env_hi - self.env_lo
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _capi.TrexError(-5, "TrexVecEnv needs a HIP device; the physics step has no CPU fallback")
+        self.model = _capi.Model(urdf_path, collisions_dir)
+        # NUM_SUBSTEPS = 5 physics substeps per action repeat (trex_env.py:18,71-73)
+        self.model.set_param("substeps", 5 * int(action_repeat))
+        for k, v in (params or {}).items():
+            self.model.set_param(k, v)
+        for name, angle in (starting_configuration or {}).items():
+            self.model.set_start_angle(name, angle)  # unknown name raises, like KeyError at trex_robot.py:307
+        self.batch = _capi.Batch(self.model, self.num_envs, self.device.index or 0)
+        self.batch.set_reward_weights(distance_weight, energy_weight, drift_weight)
+        J = self.J = self.model.num_joints
+        lo, hi = self.model.lower.astype(np.float32), self.model.upper.astype(np.float32)
+        self.action_space = spaces.Box(low=lo, high=hi, dtype=np.float32)  # trex_robot.py:424-433
+        big = np.full(2 * J, 1.0e12, np.float32)                            # trex_robot.py:348-357
+        self.observation_space = spaces.Box(low=np.concatenate([lo, -big]), high=np.concatenate([hi, big]),
+                                            dtype=np.float32)
+        n = self.num_envs
+        self.obs = torch.zeros(n, 3 * J, device=self.device)
+        self.rew = torch.zeros(n, device=self.device)
+        self.done = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        self.penalties = torch.zeros(n, 3, device=self.device)
+        self.episode_steps = torch.zeros(n, dtype=torch.int32, device=self.device)
+        self.max_episode_steps = max_episode_steps
+        self._actions = None
+        self._gather_buf = None
+
+    # ---- tensor-native API (stays on device, stream-ordered, no host sync)
+    def reset_tensor(self, mask=None):
+        """Reset all envs (mask=None) or those with mask != 0 (uint8 [n]). Returns obs [n, 3J]."""
+        self.batch.reset(self.obs, mask)
+        if mask is None:
+            self.episode_steps.zero_()
+        else:
+            self.episode_steps.masked_fill_(mask.bool(), 0)
+        return self.obs
+
+    def step_tensor(self, actions):
+        """actions [n, J] f32 on device -> (obs [n,3J], reward [n], done [n] bool). Views into buffers
+        that the next call overwrites."""
+        if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self.device:
+            actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
+        if tuple(actions.shape) != (self.num_envs, self.J):
+            raise ValueError("actions must have shape (%d, %d), got %s" % (self.num_envs, self.J, tuple(actions.shape)))
+        self.batch.step(actions, self.obs, self.rew, self.done, self.penalties)
+        done = self.done.bool()
+        if self.max_episode_steps is not None:
+            # VecEnv auto-reset without a host sync: the masked reset kernel is launched every step
+            # (teams whose mask is 0 skip the physics) and obs becomes that of the new episode.
+            self.episode_steps += 1
+            done = self.episode_steps >= self.max_episode_steps
+            self.batch.reset(self.obs, done.to(torch.uint8))
+            self.episode_steps.masked_fill_(done, 0)
+        return self.obs, self.rew, done
+
+    def all_gather_obs(self, obs=None):
+        """[global N, 3J] on every rank: the one collective of the path (RCCL all-gather over xGMI;
+        gloo in the CPU tests)."""
+        obs = self.obs if obs is None else obs
+        if self.world_size == 1:
+            return obs
+        self._gather_buf = sharding.all_gather_rows(obs, self.global_num_envs, self.world_size,
+                                                    self.process_group, out=self._gather_buf)
+        return self._gather_buf
+
+    # ---- baselines VecEnv API (host numpy in/out)
+    def reset(self):
+        return self.reset_tensor().cpu().numpy()
+
+    def step_async(self, actions):
+        self._actions = torch.as_tensor(np.asarray(actions, np.float32)).to(self.device, non_blocking=True)
+
+    def step_wait(self):
+        obs, rew, done = self.step_tensor(self._actions)
+        infos = [{} for _ in range(self.num_envs)]
+        return obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy(), infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self):
+        self.batch.close()
+
+    def render(self, mode="rgb_array"):
+        return np.array([])  # rendering is outside the accelerated path
+
+    def seed(self, seed=None):
+        return [seed]  # the env is deterministic; np_random is never consumed (trex_env.py:124-126)
+
+    # ---- state access for tests / checkpointing
+    def get_state(self):
+        out = torch.zeros(self.num_envs, self.batch.state_width, device=self.device)
+        self.batch.get_state(out)
+        return out
+
+    def set_state(self, state, motors_enabled=True):
+        state = state.to(device=self.device, dtype=torch.float32).contiguous()
+        assert tuple(state.shape) == (self.num_envs, self.batch.state_width)
+        self.batch.set_state(state)
+        self.batch.set_motors_enabled(motors_enabled)
+
+    def head_position(self):
+        out = torch.zeros(self.num_envs, 3, device=self.device)
+        self.batch.head_position(out)
+        return out
+
+    def set_domain(self, mass_scale=None, friction=None):
+        """Per-env domain randomisation (BASELINE config 5): mass_scale [n, num_bodies], friction [n]."""
+        if mass_scale is not None:
+            mass_scale = mass_scale.to(device=self.device, dtype=torch.float32).contiguous()
+            assert tuple(mass_scale.shape) == (self.num_envs, self.model.num_bodies)
+        if friction is not None:
+            friction = friction.to(device=self.device, dtype=torch.float32).contiguous()
+            assert tuple(friction.shape) == (self.num_envs,)
+        self.batch.set_domain(mass_scale, friction)
