@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 --kernel-trace --stats run of bench.py into profiles/<name>.md:
+per-kernel totals (from *_kernel_stats.csv) and, for the step kernel, the average over the timed
+region = its last K dispatches (bench.py --steps K), which is what roofline.kernel_ms reports."""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def main():
+    prof_dir, out_md, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    bench_json = sys.argv[4] if len(sys.argv) > 4 else None
+    stats = glob.glob(os.path.join(prof_dir, "**", "*_kernel_stats.csv"), recursive=True)[0]
+    trace = glob.glob(os.path.join(prof_dir, "**", "*_kernel_trace.csv"), recursive=True)[0]
+    rows = list(csv.DictReader(open(stats)))
+    lines = ["# rocprofv3 --kernel-trace --stats summary", "",
+             "command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps %d ...`" % steps, "",
+             "| kernel | calls | total ms | avg us | % | min us | max us |", "|---|---|---|---|---|---|---|"]
+    for r in rows[:8]:
+        name = r["Name"].split("(")[0][-60:]
+        lines.append("| %s | %s | %.2f | %.1f | %s | %.1f | %.1f |" % (
+            name, r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, r["Percentage"],
+            float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
+    t = [r for r in csv.DictReader(open(trace)) if "trex_step_kernel<false>" in r["Kernel_Name"]]
+    t.sort(key=lambda r: int(r["Start_Timestamp"]))
+    d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in t]
+    timed = d[-steps:]
+    lines += ["", "step kernel `trex_step_kernel<false>`: %d dispatches; timed region (last %d): avg %.3f ms, min %.3f, max %.3f"
+              % (len(d), len(timed), sum(timed) / len(timed) / 1e6, min(timed) / 1e6, max(timed) / 1e6)]
+    r0 = t[-1]
+    keys = [k for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size") if k in r0]
+    lines.append("dispatch: " + ", ".join("%s=%s" % (k, r0[k]) for k in keys))
+    if bench_json and os.path.exists(bench_json):
+        b = json.loads(open(bench_json).read().strip().splitlines()[-1])
+        lines += ["", "bench.py line of the same run: value %.0f %s, ms_per_step %.3f, roofline.kernel_ms %.3f (HIP events), "
+                  "achieved %.3f GB/s of %.0f" % (b["value"], b["unit"], b["ms_per_step"], b["roofline"]["kernel_ms"],
+                                                   b["roofline"]["achieved"], b["roofline"]["peak"])]
+    open(out_md, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()

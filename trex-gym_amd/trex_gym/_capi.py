@@ -7,6 +7,8 @@ import ctypes as C
 import os
 
 import numpy as np
+import torch  # noqa: F401  - FIRST: torch brings its own HIP runtime; loading libtrex_hip.so before it
+#                             would bind the system runtime and leave the process with two of them
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtrex_hip.so")
