@@ -38,10 +38,26 @@ namespace {
 // ---------------------------------------------------------------- team (32-lane) primitives
 __device__ __forceinline__ float tshfl(float v, int src) { return __shfl(v, src, TL); }
 __device__ __forceinline__ int tshfl(int v, int src) { return __shfl(v, src, TL); }
+// all-reduce sum over the 32 lanes of a team on the VALU (no LDS round trips): four DPP adds inside
+// the 16-lane rows, then gfx950's v_permlane16_swap exchanges row 0<->1 and 2<->3.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float tsum(float v) {
-#pragma unroll
-  for (int m = TL / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, TL);
-  return v;
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// value held by team lane `src` (src WAVE-uniform), through SGPRs: two v_readlane + one select
+__device__ __forceinline__ float tbcast(float v, int src) {
+  const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+  const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src + 32));
+  return (threadIdx.x & 32) ? b : a;
 }
 __device__ __forceinline__ unsigned tballot(bool p) {
   unsigned long long b = __ballot(p);
@@ -182,10 +198,7 @@ __device__ __forceinline__ void inv21_mul(const float *inv21, const float *v, fl
 // ---------------------------------------------------------------- LDS layout (per team)
 struct TeamLds {
   float minv[TL - 7][TL];   // [j-1][dof lane]: column j of M^-1 (j = joint/body 1..25)        3200 B
-  union {
-    float aba[TL][28];      // tip-to-base staging: Ia (21) + pa (6) per body                   3584 B
-    float W[MAXC][3][TL];   // response vectors of the contact rows                             6144 B
-  };
+  float aba[TL][28];        // tip-to-base staging: Ia (21) + pa (6) per body                   3584 B
 };
 
 struct KernelArgs {
@@ -223,7 +236,9 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
   const int bdof = lane - nb;  // 0..5 on base dof lanes
   const bool is_base_dof = bdof >= 0 && bdof < 6;
 
-  // ---- model constants of this lane's body
+  // ---- model constants of this lane's body. Topology (integers) stays in registers for the whole
+  // launch; the geometric constants (24 floats) are re-read from the L2-resident model at the top of
+  // every substep instead of being carried - and spilled - across the solver loop.
   const int parent = is_body ? M->parent[lane] : 0;
   const int psrc = parent < 0 ? 0 : parent;
   const int depth = is_body ? M->depth[lane] : -1;
@@ -233,18 +248,20 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
 #pragma unroll
   for (int k = 0; k < MAXCH; k++) child[k] = is_body ? M->child[k][lane] : -1;
   const unsigned desc_mask = M->desc_mask[lane];
-  float axis[3], jpos[3], jrot[9], comb[3], inb[6];
+  float axis[3], jpos[3], jrot[9], comb[3], inb[6], sph[4];
+  auto load_body_constants = [&](const TrexDeviceModel *Mi) {
 #pragma unroll
-  for (int c = 0; c < 3; c++) { axis[c] = M->axis[c][lane]; jpos[c] = M->jpos[c][lane]; comb[c] = M->com[c][lane]; }
+    for (int c = 0; c < 3; c++) { axis[c] = Mi->axis[c][lane]; jpos[c] = Mi->jpos[c][lane]; comb[c] = Mi->com[c][lane]; }
 #pragma unroll
-  for (int c = 0; c < 9; c++) jrot[c] = M->jrot[c][lane];
+    for (int c = 0; c < 9; c++) jrot[c] = Mi->jrot[c][lane];
 #pragma unroll
-  for (int c = 0; c < 6; c++) inb[c] = M->inertia[c][lane];
+    for (int c = 0; c < 6; c++) inb[c] = Mi->inertia[c][lane];
+#pragma unroll
+    for (int c = 0; c < 4; c++) sph[c] = Mi->sphere[c][lane];
+  };
+  load_body_constants(M);
   const float q_lo = M->lower[lane], q_hi = M->upper[lane], jdamp = M->damp[lane];
   const int hull_v0 = M->hull_start[lane < nb ? lane : nb], hull_v1 = M->hull_start[lane < nb ? lane + 1 : nb];
-  float sph[4];
-#pragma unroll
-  for (int c = 0; c < 4; c++) sph[c] = M->sphere[c][lane];
   const int obs_slot = is_joint ? M->obs_slot[lane] : -1;
   const int nj = nb - 1;
 
@@ -351,6 +368,11 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
 
   for (int sub = 0; sub < n_sub_wave; sub++) {
     const bool live = sub < n_sub;  // this team really advances
+    {
+      const TrexDeviceModel *Mi = M;
+      asm volatile("" : "+s"(Mi));  // opaque per iteration: keeps the reload inside the loop
+      load_body_constants(Mi);
+    }
     forward_kinematics();
     float vel[6];
     body_velocities(bw, bv, qd, vel);
@@ -564,7 +586,6 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       for (int d = 0; d < MAXD; d++) w += (ca[d] >= 0 && ca[d] == anc[d]) ? Aanc[d] * zc[d] : 0.f;
       return w;
     };
-    __syncthreads();  // aba staging is dead; W aliases it
     // ---- joint columns of M^-1 into LDS; diagonal kept in the joint's own lane
     float mdiag = 1.f;
     for (int j = 1; j < nb; j++) {
@@ -763,85 +784,86 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       }
     }
     const int ncw = max(nc, __shfl_xor(nc, 32));  // both teams walk the same number of points
-    for (int c = 0; c < ncw; c++) {
-      int ca[MAXD];
+    // Per point c (static index -> registers): this dof lane's Jacobian entries Jc[c][a] = velocity of
+    // the point per unit dof rate along normal z / friction x / friction y, and the response Wc[c][a].
+    float Jc[MAXC][3], Wc[MAXC][3];
 #pragma unroll
-      for (int d = 0; d < MAXD; d++) ca[d] = tshfl(c_anc[d], c);
+    for (int c = 0; c < MAXC; c++) {
 #pragma unroll
-      for (int a = 0; a < 3; a++) {
-        float zc[MAXD], z0[6];
+      for (int a = 0; a < 3; a++) { Jc[c][a] = 0.f; Wc[c][a] = 0.f; }
+      if (c < ncw) {
+        int ca[MAXD];
 #pragma unroll
-        for (int d = 0; d < MAXD; d++) zc[d] = tshfl(c_zc[a][d], c);
+        for (int d = 0; d < MAXD; d++) ca[d] = tshfl(c_anc[d], c);
+        float x[3];
 #pragma unroll
-        for (int k = 0; k < 6; k++) z0[k] = tshfl(c_z0[a][k], c);
-        lds.W[c][a][lane] = (c < nc) ? response(ca, zc, z0) : 0.f;
+        for (int k = 0; k < 3; k++) x[k] = tshfl(cx[k], c);
+        const int b = tshfl(cbody, c);
+        float wx[3];
+        cross3(Sd, x, wx);
+        const bool on = (c < nc) && ((desc_mask >> b) & 1u);
+        Jc[c][0] = on ? Sd[5] + wx[2] : 0.f;
+        Jc[c][1] = on ? Sd[3] + wx[0] : 0.f;
+        Jc[c][2] = on ? Sd[4] + wx[1] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          float zc[MAXD], z0[6];
+#pragma unroll
+          for (int d = 0; d < MAXD; d++) zc[d] = tshfl(c_zc[a][d], c);
+#pragma unroll
+          for (int k = 0; k < 6; k++) z0[k] = tshfl(c_z0[a][k], c);
+          Wc[c][a] = (c < nc) ? response(ca, zc, z0) : 0.f;
+        }
       }
     }
     __syncthreads();
 
     // ---- projected Gauss-Seidel, velocity level. Row order = oracle: limits, motors, contacts.
+    // The owning lane (joint j / contact c) computes the impulse change from registers, two
+    // v_readlane broadcast it, every dof lane applies its response entry. Only contact rows reduce.
     float dv = 0.f;
     const unsigned lim_wave = lim_mask | (unsigned)__shfl_xor((int)lim_mask, 32);
+    const float fr_mu = mu;
     for (int it = 0; it < iters; it++) {
       if (lim_wave) {
-        for (int j = 1; j < nb; j++) {
-          if (!((lim_wave >> j) & 1u)) continue;
-          float delta = 0.f;
-          if (lane == j && lim_dir != 0.f) {
-            float nl = lim_lam + (lim_rhs - lim_dir * dv * inv_mdiag);
-            nl = fmaxf(nl, 0.f);
-            delta = (nl - lim_lam) * lim_dir;
-            lim_lam = nl;
+#pragma unroll
+        for (int j = 1; j < TL - 6; j++) {
+          if ((lim_wave >> j) & 1u) {
+            float nl = fmaxf(lim_lam + (lim_rhs - lim_dir * dv * inv_mdiag), 0.f);
+            float delta = (nl - lim_lam) * lim_dir;   // lim_dir == 0 on lanes without an active row
+            if (lane == j) lim_lam = nl;
+            delta = tbcast(delta, j);
+            dv += delta * lds.minv[j - 1][lane];
           }
-          delta = tshfl(delta, j);
+        }
+      }
+#pragma unroll
+      for (int j = 1; j < TL - 6; j++) {
+        if (j < nb) {
+          float nl = fminf(fmaxf(mot_lam + (mot_rhs - dv * inv_mdiag), -mot_hi), mot_hi);
+          float delta = nl - mot_lam;
+          if (lane == j) mot_lam = nl;
+          delta = tbcast(delta, j);
           dv += delta * lds.minv[j - 1][lane];
         }
       }
-      for (int j = 1; j < nb; j++) {
-        float delta = 0.f;
-        if (lane == j) {
-          float nl = mot_lam + (mot_rhs - dv * inv_mdiag);
-          nl = fminf(fmaxf(nl, -mot_hi), mot_hi);
-          delta = nl - mot_lam;
-          mot_lam = nl;
-        }
-        delta = tshfl(delta, j);
-        dv += delta * lds.minv[j - 1][lane];
-      }
-      for (int c = 0; c < ncw; c++) {
-        // Jacobian entries of this dof lane for point c: velocity of the point per unit dof rate
-        float x[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) x[k] = tshfl(cx[k], c);
-        const int b = tshfl(cbody, c);
-        float J[3];
-        {
-          float wx[3];
-          cross3(Sd, x, wx);
-          const bool on = (c < nc) && ((desc_mask >> b) & 1u);
-          // order: normal (z), friction x, friction y
-          J[0] = on ? Sd[5] + wx[2] : 0.f;
-          J[1] = on ? Sd[3] + wx[0] : 0.f;
-          J[2] = on ? Sd[4] + wx[1] : 0.f;
-        }
+      for (int c = 0; c < MAXC; c++) {
+        if (c < ncw) {
 #pragma unroll
-        for (int a = 0; a < 3; a++) {
-          const float jdv = tsum(J[a] * dv);
-          float delta = 0.f;
-          if (lane == c) {
-            float lo = 0.f, hi = 1.0e30f;
-            if (a > 0) { hi = mu * c_lam[0]; lo = -hi; }
-            float nl = c_lam[a] + (c_rhs[a] - jdv * c_inv[a]);
-            nl = fminf(fmaxf(nl, lo), hi);
-            delta = nl - c_lam[a];
-            c_lam[a] = nl;
+          for (int a = 0; a < 3; a++) {
+            const float jdv = tsum(Jc[c][a] * dv);
+            const float hi = (a == 0) ? 1.0e30f : fr_mu * c_lam[0];
+            const float lo = (a == 0) ? 0.f : -hi;
+            const float nl = fminf(fmaxf(c_lam[a] + (c_rhs[a] - jdv * c_inv[a]), lo), hi);
+            float delta = nl - c_lam[a];
+            if (lane == c) c_lam[a] = nl;
+            delta = tbcast(delta, c);
+            dv += delta * Wc[c][a];
           }
-          delta = tshfl(delta, c);
-          dv += delta * lds.W[c][a][lane];
         }
       }
     }
-    __syncthreads();
 
     if (args.debug && blockIdx.x == 0 && team == 0) {
       float *D = args.debug;
@@ -855,8 +877,10 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
 #pragma unroll
         for (int a = 0; a < 3; a++) { C[5 + a] = c_inv[a]; C[8 + a] = c_rhs[a]; C[11 + a] = c_lam[a]; }
       }
-      for (int c = 0; c < nc; c++)
-        for (int a = 0; a < 3; a++) D[1216 + (c * 3 + a) * 32 + lane] = lds.W[c][a][lane];
+#pragma unroll
+      for (int c = 0; c < MAXC; c++)
+        if (c < nc)
+          for (int a = 0; a < 3; a++) D[1216 + (c * 3 + a) * 32 + lane] = Wc[c][a];
     }
     __syncthreads();
 
@@ -890,6 +914,11 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
   }
 
   // ---- head position (needs FK at the new pose: getLinkState(computeForwardKinematics=1))
+  {
+    const TrexDeviceModel *Mi = M;
+    asm volatile("" : "+s"(Mi));
+    load_body_constants(Mi);
+  }
   forward_kinematics();
   float head[3];
   {
