@@ -199,6 +199,7 @@ __device__ __forceinline__ void inv21_mul(const float *inv21, const float *v, fl
 struct TeamLds {
   float minv[TL - 7][TL];   // [j-1][dof lane]: column j of M^-1 (j = joint/body 1..25)        3200 B
   float aba[TL][28];        // tip-to-base staging: Ia (21) + pa (6) per body                   3584 B
+  float2 crow[MAXC][3];     // contact rows: {rhs, 1/diag}, read back as a team-wide broadcast      384 B
 };
 
 struct KernelArgs {
@@ -819,11 +820,21 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
     __syncthreads();
 
     // ---- projected Gauss-Seidel, velocity level. Row order = oracle: limits, motors, contacts.
-    // The owning lane (joint j / contact c) computes the impulse change from registers, two
-    // v_readlane broadcast it, every dof lane applies its response entry. Only contact rows reduce.
+    // Joint rows: the owning lane j computes the impulse change from its own registers, two
+    // v_readlane broadcast it, every dof lane applies its M^-1 entry (LDS).
+    // Contact rows: J.dv is all-reduced on the VALU, so EVERY lane can finish the row redundantly:
+    // {rhs, 1/diag} arrive as an LDS broadcast (prefetchable, off the dependent chain), the impulses
+    // lam[c][a] are kept replicated in registers - no broadcast of the result is needed.
+    if (lane < nc) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) lds.crow[lane][a] = make_float2(c_rhs[a], c_inv[a]);
+    }
+    __syncthreads();
+    float lam[MAXC][3];
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) { lam[c][0] = 0.f; lam[c][1] = 0.f; lam[c][2] = 0.f; }
     float dv = 0.f;
     const unsigned lim_wave = lim_mask | (unsigned)__shfl_xor((int)lim_mask, 32);
-    const float fr_mu = mu;
     for (int it = 0; it < iters; it++) {
       if (lim_wave) {
 #pragma unroll
@@ -840,7 +851,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
 #pragma unroll
       for (int j = 1; j < TL - 6; j++) {
         if (j < nb) {
-          float nl = fminf(fmaxf(mot_lam + (mot_rhs - dv * inv_mdiag), -mot_hi), mot_hi);
+          const float nl = __builtin_amdgcn_fmed3f(mot_lam + (mot_rhs - dv * inv_mdiag), -mot_hi, mot_hi);
           float delta = nl - mot_lam;
           if (lane == j) mot_lam = nl;
           delta = tbcast(delta, j);
@@ -852,17 +863,21 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
         if (c < ncw) {
 #pragma unroll
           for (int a = 0; a < 3; a++) {
+            const float2 ri = lds.crow[c][a];
             const float jdv = tsum(Jc[c][a] * dv);
-            const float hi = (a == 0) ? 1.0e30f : fr_mu * c_lam[0];
+            const float hi = (a == 0) ? 1.0e30f : mu * lam[c][0];
             const float lo = (a == 0) ? 0.f : -hi;
-            const float nl = fminf(fmaxf(c_lam[a] + (c_rhs[a] - jdv * c_inv[a]), lo), hi);
-            float delta = nl - c_lam[a];
-            if (lane == c) c_lam[a] = nl;
-            delta = tbcast(delta, c);
-            dv += delta * Wc[c][a];
+            const float nl = __builtin_amdgcn_fmed3f(lam[c][a] + (ri.x - jdv * ri.y), lo, hi);
+            dv += (nl - lam[c][a]) * Wc[c][a];
+            lam[c][a] = nl;
           }
         }
       }
+    }
+    if (lane < nc) {  // hand the owner lane its impulses (diagnostics, contact statistics)
+#pragma unroll
+      for (int c = 0; c < MAXC; c++)
+        if (lane == c) { c_lam[0] = lam[c][0]; c_lam[1] = lam[c][1]; c_lam[2] = lam[c][2]; }
     }
 
     if (args.debug && blockIdx.x == 0 && team == 0) {
