@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--param", action="append", default=[],
+                    help="engine parameter override name=value (ablations only: the line is then NOT the headline config)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -105,7 +107,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n_global = args.envs_per_gpu * world
-    env = TrexVecEnv(n_global, device=dev, rank=rank, world_size=world)
+    overrides = {k: float(v) for k, v in (p.split("=") for p in args.param)}
+    env = TrexVecEnv(n_global, device=dev, rank=rank, world_size=world, params=overrides)
     n_local = env.num_envs
     lo, hi = env.model.lower, env.model.upper
     ids = torch.arange(env.env_lo, env.env_hi, device=dev)
@@ -172,7 +175,8 @@ def main():
                                    "PGS iterations per step, episode limit %d steps%s"
                                    % (args.envs_per_gpu, world, EPISODE_STEPS,
                                       ", obs all-gather over RCCL each step" if world > 1 else ""),
-                       "envs_global": n_global, "parallelism": "env-sharded dp%d" % world},
+                       "envs_global": n_global, "parallelism": "env-sharded dp%d" % world,
+                       **({"ABLATION_param_overrides": overrides} if overrides else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "trex_step_kernel<false>", "kernel_ms": kernel_ms,

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Where does a substep spend its cycles? Runs the s_memtime-stamped DIAGNOSTIC build
+(make -C trex-gym_amd/csrc stamps; TREX_LIB=...libtrex_hip_stamps.so) with 4096 envs in a
+contact-rich state and prints workgroup 0's cycle shares per phase. Shares, not lengths, are
+meaningful (the stamps fence the scheduler)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+os.environ.setdefault("TREX_LIB", os.path.join(ROOT, "trex-gym_amd", "trex_gym", "libtrex_hip_stamps.so"))
+sys.path.insert(0, os.path.join(ROOT, "trex-gym_amd"))
+from trex_gym import _capi, sharding  # noqa: E402
+
+NAMES = ["FK + velocities", "inertia, bias", "ABA pass 2 (LDS)", "base 6x6 inverse", "ABA pass 3 + vel update",
+         "factorisation A", "M^-1 joint columns", "joint rows", "contact generation", "contact chain walk",
+         "J / W blocks", "K couplings + row constants", "PGS (60 sweeps)", "integrate"]
+
+
+def main():
+    dev = torch.device("cuda:0")
+    n = 4096
+    m = _capi.Model()
+    b = _capi.Batch(m, n)
+    obs = torch.zeros(n, 75, device=dev); rew = torch.zeros(n, device=dev); done = torch.zeros(n, dtype=torch.uint8, device=dev)
+    b.reset(obs)
+    ids = torch.arange(n, device=dev)
+    for t in range(60):
+        b.step(sharding.synthetic_actions(ids, t, m.lower, m.upper, device=dev), obs, rew, done)
+    dbg = torch.zeros(4096, device=dev)
+    tot = np.zeros(14)
+    for t in range(60, 70):
+        b.debug_step(sharding.synthetic_actions(ids, t, m.lower, m.upper, device=dev), obs, dbg)
+        torch.cuda.synchronize()
+        d = dbg.cpu().numpy()
+        tot += d[3000:3000 + 80].reshape(5, 16)[:, :14].sum(0)
+    cnt = torch.zeros(n, dtype=torch.int32, device=dev)
+    b.contact_stats(cnt, None)
+    print("contacts per env: mean %.1f max %d (env0 %d)" % (cnt.float().mean().item(), cnt.max().item(), cnt[0].item()))
+    tot /= 10
+    for name, c in zip(NAMES, tot):
+        print("%-32s %9.0f cycles  %5.1f %%" % (name, c, 100 * c / tot.sum()))
+    print("%-32s %9.0f cycles per env-step (5 substeps)" % ("total", tot.sum()))
+
+
+if __name__ == "__main__":
+    main()

@@ -33,6 +33,25 @@
 #define MAXCH TREX_MAXCH
 #define MAXC TREX_MAXC
 
+#ifndef TREX_STAMPS
+#define TREX_STAMPS 0
+#endif
+// Diagnostic build only (make stamps): s_memtime at phase boundaries of workgroup 0, written to the
+// debug buffer at [3000 + 16*substep + phase] as cycle deltas. Never compiled into the product library.
+#if TREX_STAMPS
+#define STAMP(i)                                                                          \
+  do {                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    const unsigned long long _t = __builtin_amdgcn_s_memtime();                           \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                                   \
+    if (args.debug && blockIdx.x == 0 && threadIdx.x == 0) args.debug[3000 + 16 * sub + (i)] = (float)(_t - stamp_last); \
+    stamp_last = _t;                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+  } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
 namespace {
 
 // ---------------------------------------------------------------- team (32-lane) primitives
@@ -196,11 +215,14 @@ __device__ __forceinline__ void inv21_mul(const float *inv21, const float *v, fl
 }
 
 // ---------------------------------------------------------------- LDS layout (per team)
+constexpr int NJMAX = TL - 7;   // 25 hinge joints at most (26 bodies + 6 base dofs = 32 lanes)
 struct TeamLds {
-  float minv[TL - 7][TL];   // [j-1][dof lane]: column j of M^-1 (j = joint/body 1..25)        3200 B
-  float aba[TL][28];        // tip-to-base staging: Ia (21) + pa (6) per body                   3584 B
-  float2 crow[MAXC][3];     // contact rows: {rhs, 1/diag}, read back as a team-wide broadcast      384 B
+  float cst[28][TL];        // this team's body constants, re-read every substep (not carried in VGPRs) 3584 B
+  float aba[TL][28];        // tip-to-base staging: Ia (21) + pa (6) per body; afterwards reused as the
+                            // broadcast stage for the M^-1 columns and the contact blocks        3584 B
+  float4 crow[MAXC * 3];    // contact rows: {rhs, 1/diag, K1, K2}, read back as a team broadcast   768 B
 };
+static_assert(sizeof(float) * TL * 28 >= sizeof(float) * MAXC * 52, "contact stage must fit the aba region");
 
 struct KernelArgs {
   const TrexDeviceModel *model;
@@ -250,17 +272,28 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
   for (int k = 0; k < MAXCH; k++) child[k] = is_body ? M->child[k][lane] : -1;
   const unsigned desc_mask = M->desc_mask[lane];
   float axis[3], jpos[3], jrot[9], comb[3], inb[6], sph[4];
-  auto load_body_constants = [&](const TrexDeviceModel *Mi) {
+  {
+    // one global read per launch; every substep re-reads the 28 floats from LDS
 #pragma unroll
-    for (int c = 0; c < 3; c++) { axis[c] = Mi->axis[c][lane]; jpos[c] = Mi->jpos[c][lane]; comb[c] = Mi->com[c][lane]; }
+    for (int c = 0; c < 3; c++) { lds.cst[c][lane] = M->axis[c][lane]; lds.cst[3 + c][lane] = M->jpos[c][lane]; lds.cst[6 + c][lane] = M->com[c][lane]; }
 #pragma unroll
-    for (int c = 0; c < 9; c++) jrot[c] = Mi->jrot[c][lane];
+    for (int c = 0; c < 9; c++) lds.cst[9 + c][lane] = M->jrot[c][lane];
 #pragma unroll
-    for (int c = 0; c < 6; c++) inb[c] = Mi->inertia[c][lane];
+    for (int c = 0; c < 6; c++) lds.cst[18 + c][lane] = M->inertia[c][lane];
 #pragma unroll
-    for (int c = 0; c < 4; c++) sph[c] = Mi->sphere[c][lane];
+    for (int c = 0; c < 4; c++) lds.cst[24 + c][lane] = M->sphere[c][lane];
+  }
+  __syncthreads();
+  auto load_body_constants = [&]() {
+#pragma unroll
+    for (int c = 0; c < 3; c++) { axis[c] = lds.cst[c][lane]; jpos[c] = lds.cst[3 + c][lane]; comb[c] = lds.cst[6 + c][lane]; }
+#pragma unroll
+    for (int c = 0; c < 9; c++) jrot[c] = lds.cst[9 + c][lane];
+#pragma unroll
+    for (int c = 0; c < 6; c++) inb[c] = lds.cst[18 + c][lane];
+#pragma unroll
+    for (int c = 0; c < 4; c++) sph[c] = lds.cst[24 + c][lane];
   };
-  load_body_constants(M);
   const float q_lo = M->lower[lane], q_hi = M->upper[lane], jdamp = M->damp[lane];
   const int hull_v0 = M->hull_start[lane < nb ? lane : nb], hull_v1 = M->hull_start[lane < nb ? lane + 1 : nb];
   const int obs_slot = is_joint ? M->obs_slot[lane] : -1;
@@ -369,15 +402,15 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
 
   for (int sub = 0; sub < n_sub_wave; sub++) {
     const bool live = sub < n_sub;  // this team really advances
-    {
-      const TrexDeviceModel *Mi = M;
-      asm volatile("" : "+s"(Mi));  // opaque per iteration: keeps the reload inside the loop
-      load_body_constants(Mi);
-    }
+#if TREX_STAMPS
+    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+#endif
+    load_body_constants();
     forward_kinematics();
     float vel[6];
     body_velocities(bw, bv, qd, vel);
 
+    STAMP(0);
     // ---- rigid-body spatial inertia about O, bias force, velocity-product acceleration
     float comw[3], Icw[6];
     {
@@ -456,6 +489,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       }
     }
 
+    STAMP(1);
     // ---- ABA pass 2 (tip to base): articulated inertias and bias forces through LDS
     float U[6], Ud[6], invD = 0.f, u = 0.f;
 #pragma unroll
@@ -498,6 +532,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       __syncthreads();
     }
 
+    STAMP(2);
     // ---- floating base: a0 = -(IA_0)^-1 pA_0 ; broadcast the inverse to the whole team
     float I0inv[21], a0[6];
     {
@@ -510,6 +545,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       for (int k = 0; k < 6; k++) p0[k] = -tshfl(pA[k], 0);
       inv21_mul(I0inv, p0, a0);
     }
+    STAMP(3);
     // ---- ABA pass 3 (base to tip): accelerations
     float qdd = 0.f;
     {
@@ -550,6 +586,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       if (is_base_dof && bdof == k) vg = (k < 3) ? nw[k] : nv[k - 3];
     }
 
+    STAMP(4);
     // ---- distributed factorisation M^-1 = A^T B A: this lane's column of A
     //   Aanc[d-1] = entry at its ancestor of depth d (1 at its own depth), A0 = base block entry,
     //   Z[d-1]    = Aanc[d-1] / D(ancestor), g = I0inv * A0
@@ -587,20 +624,39 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       for (int d = 0; d < MAXD; d++) w += (ca[d] >= 0 && ca[d] == anc[d]) ? Aanc[d] * zc[d] : 0.f;
       return w;
     };
-    // ---- joint columns of M^-1 into LDS; diagonal kept in the joint's own lane
+    STAMP(5);
+    // ---- joint columns of M^-1 (response vectors of the motor / limit rows) into REGISTERS:
+    // mcol[j-1] = M^-1[this dof lane][joint j]. Every lane publishes its column of A once (18 floats,
+    // staged in the dead aba region) and reads joint j's as a team-wide LDS broadcast.
+    __syncthreads();
+    {
+      float *o = lds.aba[lane];
+#pragma unroll
+      for (int d = 0; d < MAXD; d++) { o[d] = __int_as_float(anc[d]); o[6 + d] = Z[d]; }
+#pragma unroll
+      for (int k = 0; k < 6; k++) o[12 + k] = g[k];
+    }
+    __syncthreads();
+    float mcol[NJMAX];
     float mdiag = 1.f;
-    for (int j = 1; j < nb; j++) {
-      int ca[MAXD];
-      float zc[MAXD], z0[6];
 #pragma unroll
-      for (int d = 0; d < MAXD; d++) { ca[d] = tshfl(anc[d], j); zc[d] = tshfl(Z[d], j); }
+    for (int j = 1; j <= NJMAX; j++) {
+      mcol[j - 1] = 0.f;
+      if (j < nb) {
+        const float *o = lds.aba[j];
+        int ca[MAXD];
+        float zc[MAXD], z0[6];
 #pragma unroll
-      for (int k = 0; k < 6; k++) z0[k] = tshfl(g[k], j);
-      const float w = response(ca, zc, z0);
-      lds.minv[j - 1][lane] = w;
-      if (lane == j) mdiag = w;
+        for (int d = 0; d < MAXD; d++) { ca[d] = __float_as_int(o[d]); zc[d] = o[6 + d]; }
+#pragma unroll
+        for (int k = 0; k < 6; k++) z0[k] = o[12 + k];
+        const float w = response(ca, zc, z0);
+        mcol[j - 1] = w;
+        if (lane == j) mdiag = w;
+      }
     }
 
+    STAMP(6);
     // ---- joint rows: limits (unilateral, ERP) and position motors
     const float inv_mdiag = 1.0f / mdiag;
     float lim_dir = 0.f, lim_rhs = 0.f, lim_lam = 0.f;
@@ -619,6 +675,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       mot_rhs = (tv - vg) * inv_mdiag;
     }
 
+    STAMP(7);
     // ---- contact generation: hull vertices against z <= floor_z
     int nc = 0;
     int cbody = 0;
@@ -720,6 +777,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       }
     }
 
+    STAMP(8);
     // ---- contact rows: lane c owns point c and walks its body's chain for the three directions
     //      (normal z, friction x, friction y); everything below is per lane, no reductions.
     float c_rhs[3] = {0.f, 0.f, 0.f}, c_inv[3] = {0.f, 0.f, 0.f}, c_lam[3] = {0.f, 0.f, 0.f};
@@ -784,22 +842,38 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
         c_rhs[a] = (tv - dot3(dirs[a], pvel)) * c_inv[a];
       }
     }
+    STAMP(9);
     const int ncw = max(nc, __shfl_xor(nc, 32));  // both teams walk the same number of points
     // Per point c (static index -> registers): this dof lane's Jacobian entries Jc[c][a] = velocity of
     // the point per unit dof rate along normal z / friction x / friction y, and the response Wc[c][a].
+    // Lane c publishes its point (chain, z-coefficients, position, body: 46 floats) in the stage.
+    __syncthreads();
+    if (lane < MAXC) {
+      float *o = reinterpret_cast<float *>(lds.aba) + lane * 52;
+#pragma unroll
+      for (int d = 0; d < MAXD; d++) o[d] = __int_as_float(c_anc[d]);
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int d = 0; d < MAXD; d++) o[6 + 6 * a + d] = c_zc[a][d];
+#pragma unroll
+        for (int k = 0; k < 6; k++) o[24 + 6 * a + k] = c_z0[a][k];
+      }
+      o[42] = cx[0]; o[43] = cx[1]; o[44] = cx[2]; o[45] = __int_as_float(cbody);
+    }
+    __syncthreads();
     float Jc[MAXC][3], Wc[MAXC][3];
 #pragma unroll
     for (int c = 0; c < MAXC; c++) {
 #pragma unroll
       for (int a = 0; a < 3; a++) { Jc[c][a] = 0.f; Wc[c][a] = 0.f; }
       if (c < ncw) {
+        const float *o = reinterpret_cast<const float *>(lds.aba) + c * 52;
         int ca[MAXD];
 #pragma unroll
-        for (int d = 0; d < MAXD; d++) ca[d] = tshfl(c_anc[d], c);
-        float x[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) x[k] = tshfl(cx[k], c);
-        const int b = tshfl(cbody, c);
+        for (int d = 0; d < MAXD; d++) ca[d] = __float_as_int(o[d]);
+        const float x[3] = {o[42], o[43], o[44]};
+        const int b = __float_as_int(o[45]);
         float wx[3];
         cross3(Sd, x, wx);
         const bool on = (c < nc) && ((desc_mask >> b) & 1u);
@@ -810,70 +884,92 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
         for (int a = 0; a < 3; a++) {
           float zc[MAXD], z0[6];
 #pragma unroll
-          for (int d = 0; d < MAXD; d++) zc[d] = tshfl(c_zc[a][d], c);
+          for (int d = 0; d < MAXD; d++) zc[d] = o[6 + 6 * a + d];
 #pragma unroll
-          for (int k = 0; k < 6; k++) z0[k] = tshfl(c_z0[a][k], c);
+          for (int k = 0; k < 6; k++) z0[k] = o[24 + 6 * a + k];
           Wc[c][a] = (c < nc) ? response(ca, zc, z0) : 0.f;
         }
       }
     }
     __syncthreads();
 
-    // ---- projected Gauss-Seidel, velocity level. Row order = oracle: limits, motors, contacts.
-    // Joint rows: the owning lane j computes the impulse change from its own registers, two
-    // v_readlane broadcast it, every dof lane applies its M^-1 entry (LDS).
-    // Contact rows: J.dv is all-reduced on the VALU, so EVERY lane can finish the row redundantly:
-    // {rhs, 1/diag} arrive as an LDS broadcast (prefetchable, off the dependent chain), the impulses
-    // lam[c][a] are kept replicated in registers - no broadcast of the result is needed.
-    if (lane < nc) {
+    STAMP(10);
+    // Pipelined Gauss-Seidel over the contact rows: the reduction J_r.dv of row r is started two rows
+    // early from the dv of that moment and completed with the scalar couplings K1_r = J_r.W_(r-1),
+    // K2_r = J_r.W_(r-2) once those rows' impulse changes are known - identical arithmetic up to
+    // rounding (J.(dv + d W) = J.dv + d (J.W)), but the dependent chain per row shrinks from
+    // reduce+solve (13 ops) to correct+solve (6 ops). Rows are processed in groups of 4 points
+    // (one basic block each, so the scheduler can overlap the two chains).
+    constexpr int GP = 4, GR = 3 * GP;
 #pragma unroll
-      for (int a = 0; a < 3; a++) lds.crow[lane][a] = make_float2(c_rhs[a], c_inv[a]);
+    for (int g = 0; g < MAXC / GP; g++) {
+      if (GP * g < ncw) {
+#pragma unroll
+        for (int k = 0; k < GR; k++) {
+          const int r = GR * g + k, c = r / 3, a = r % 3;
+          float k1 = 0.f, k2 = 0.f;
+          if (k >= 1) k1 = tsum(Jc[c][a] * Wc[(r - 1) / 3][(r - 1) % 3]);
+          if (k >= 2) k2 = tsum(Jc[c][a] * Wc[(r - 2) / 3][(r - 2) % 3]);
+          const bool own = lane == c && c < nc;
+          if (lane == c) lds.crow[r] = own ? make_float4(c_rhs[a], c_inv[a], k1, k2) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
     }
     __syncthreads();
+    STAMP(11);
     float lam[MAXC][3];
 #pragma unroll
     for (int c = 0; c < MAXC; c++) { lam[c][0] = 0.f; lam[c][1] = 0.f; lam[c][2] = 0.f; }
     float dv = 0.f;
     const unsigned lim_wave = lim_mask | (unsigned)__shfl_xor((int)lim_mask, 32);
     for (int it = 0; it < iters; it++) {
-      if (lim_wave) {
+      if (lim_wave) {   // some joint of this wave sits on a stop: all 25 limit rows, branch-free
 #pragma unroll
-        for (int j = 1; j < TL - 6; j++) {
-          if ((lim_wave >> j) & 1u) {
-            float nl = fmaxf(lim_lam + (lim_rhs - lim_dir * dv * inv_mdiag), 0.f);
-            float delta = (nl - lim_lam) * lim_dir;   // lim_dir == 0 on lanes without an active row
-            if (lane == j) lim_lam = nl;
-            delta = tbcast(delta, j);
-            dv += delta * lds.minv[j - 1][lane];
-          }
-        }
-      }
-#pragma unroll
-      for (int j = 1; j < TL - 6; j++) {
-        if (j < nb) {
-          const float nl = __builtin_amdgcn_fmed3f(mot_lam + (mot_rhs - dv * inv_mdiag), -mot_hi, mot_hi);
-          float delta = nl - mot_lam;
-          if (lane == j) mot_lam = nl;
+        for (int j = 1; j <= NJMAX; j++) {
+          const float nl = fmaxf(lim_lam + (lim_rhs - lim_dir * dv * inv_mdiag), 0.f);
+          float delta = (nl - lim_lam) * lim_dir;   // lim_dir == 0 on lanes without an active row
+          if (lane == j) lim_lam = nl;
           delta = tbcast(delta, j);
-          dv += delta * lds.minv[j - 1][lane];
+          dv += delta * mcol[j - 1];
         }
       }
 #pragma unroll
-      for (int c = 0; c < MAXC; c++) {
-        if (c < ncw) {
+      for (int j = 1; j <= NJMAX; j++) {   // joints beyond nb have mot_hi = 0 and mcol = 0
+        const float nl = __builtin_amdgcn_fmed3f(mot_lam + (mot_rhs - dv * inv_mdiag), -mot_hi, mot_hi);
+        float delta = nl - mot_lam;
+        if (lane == j) mot_lam = nl;
+        delta = tbcast(delta, j);
+        dv += delta * mcol[j - 1];
+      }
 #pragma unroll
-          for (int a = 0; a < 3; a++) {
-            const float2 ri = lds.crow[c][a];
-            const float jdv = tsum(Jc[c][a] * dv);
+      for (int g = 0; g < MAXC / GP; g++) {
+        if (GP * g < ncw) {
+          const int r0 = GR * g;
+          float4 qa = lds.crow[r0], qb = lds.crow[r0 + 1];
+          float pa = tsum(Jc[r0 / 3][0] * dv), pb = tsum(Jc[r0 / 3][1] * dv);
+#pragma unroll
+          for (int k = 0; k < GR; k++) {
+            const int r = r0 + k, c = r / 3, a = r % 3;
+            float4 qc = make_float4(0.f, 0.f, 0.f, 0.f);
+            float pc = 0.f;
+            if (k + 2 < GR) {   // start row r+2 from the dv of this moment (rows r, r+1 still missing)
+              qc = lds.crow[r + 2];
+              pc = tsum(Jc[(r + 2) / 3][(r + 2) % 3] * dv);
+            }
             const float hi = (a == 0) ? 1.0e30f : mu * lam[c][0];
             const float lo = (a == 0) ? 0.f : -hi;
-            const float nl = __builtin_amdgcn_fmed3f(lam[c][a] + (ri.x - jdv * ri.y), lo, hi);
-            dv += (nl - lam[c][a]) * Wc[c][a];
+            const float nl = __builtin_amdgcn_fmed3f(lam[c][a] + (qa.x - pa * qa.y), lo, hi);
+            const float d = nl - lam[c][a];
             lam[c][a] = nl;
+            dv += d * Wc[c][a];
+            pb += d * qb.z;                    // K1 of row r+1
+            if (k + 2 < GR) pc += d * qc.w;    // K2 of row r+2
+            pa = pb; qa = qb; pb = pc; qb = qc;
           }
         }
       }
     }
+    STAMP(12);
     if (lane < nc) {  // hand the owner lane its impulses (diagnostics, contact statistics)
 #pragma unroll
       for (int c = 0; c < MAXC; c++)
@@ -885,7 +981,8 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       D[lane] = qdd; D[64 + lane] = vg; D[96 + lane] = dv;
       if (lane < 6) D[32 + lane] = a0[lane];
       if (lane == 0) { D[128] = (float)nc; D[129] = (float)lim_mask; }
-      for (int j = 1; j < nb; j++) D[160 + 32 * (j - 1) + lane] = lds.minv[j - 1][lane];
+#pragma unroll
+      for (int j = 1; j <= NJMAX; j++) D[160 + 32 * (j - 1) + lane] = mcol[j - 1];
       if (lane < nc) {
         float *C = D + 960 + lane * 16;
         C[0] = (float)cbody; C[1] = cx[0]; C[2] = cx[1]; C[3] = cx[2]; C[4] = cdist;
@@ -926,14 +1023,11 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       stat_nc = nc;
       stat_imp = tsum(lane < nc ? c_lam[0] : 0.f);
     }
+    STAMP(13);
   }
 
   // ---- head position (needs FK at the new pose: getLinkState(computeForwardKinematics=1))
-  {
-    const TrexDeviceModel *Mi = M;
-    asm volatile("" : "+s"(Mi));
-    load_body_constants(Mi);
-  }
+  load_body_constants();
   forward_kinematics();
   float head[3];
   {

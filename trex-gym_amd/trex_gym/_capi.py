@@ -11,7 +11,7 @@ import torch  # noqa: F401  - FIRST: torch brings its own HIP runtime; loading l
 #                             would bind the system runtime and leave the process with two of them
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtrex_hip.so")
+LIB_PATH = os.environ.get("TREX_LIB") or os.path.join(_HERE, "libtrex_hip.so")  # TREX_LIB: diagnostic builds
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
