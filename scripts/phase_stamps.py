@@ -27,15 +27,21 @@ def main():
     obs = torch.zeros(n, 75, device=dev); rew = torch.zeros(n, device=dev); done = torch.zeros(n, dtype=torch.uint8, device=dev)
     b.reset(obs)
     ids = torch.arange(n, device=dev)
-    for t in range(60):
-        b.step(sharding.synthetic_actions(ids, t, m.lower, m.upper, device=dev), obs, rew, done)
+    # hold the start pose: every env lands and rests on toes + tail with 14 contact points, so that
+    # workgroup 0 (the stamped one) is a HEAVY wave - the kernel is as slow as its slowest wave
+    hold = torch.tensor(m.array("q_start")[m.array("obs_order").astype(int)], dtype=torch.float32, device=dev).repeat(n, 1)
+    for t in range(150):
+        b.step(hold, obs, rew, done)
     dbg = torch.zeros(4096, device=dev)
     tot = np.zeros(14)
-    for t in range(60, 70):
-        b.debug_step(sharding.synthetic_actions(ids, t, m.lower, m.upper, device=dev), obs, dbg)
+    joint = 0.0
+    for t in range(10):
+        b.debug_step(hold, obs, dbg)
         torch.cuda.synchronize()
         d = dbg.cpu().numpy()
         tot += d[3000:3000 + 80].reshape(5, 16)[:, :14].sum(0)
+        joint += d[3000:3000 + 80].reshape(5, 16)[:, 14].sum()
+        limw = d[3000:3000 + 80].reshape(5, 16)[:, 15]
     cnt = torch.zeros(n, dtype=torch.int32, device=dev)
     b.contact_stats(cnt, None)
     print("contacts per env: mean %.1f max %d (env0 %d)" % (cnt.float().mean().item(), cnt.max().item(), cnt[0].item()))
@@ -43,6 +49,8 @@ def main():
     for name, c in zip(NAMES, tot):
         print("%-32s %9.0f cycles  %5.1f %%" % (name, c, 100 * c / tot.sum()))
     print("%-32s %9.0f cycles per env-step (5 substeps)" % ("total", tot.sum()))
+    print("inside PGS: joint rows (limits+motors) %.0f cycles = %.1f per motor row; contact rows %.0f cycles = %.1f per row (3 x %d); limit mask %s"
+          % (joint / 10, joint / 10 / (300 * 25), tot[12] - joint / 10, (tot[12] - joint / 10) / (300 * 3 * cnt[0].item() + 1e-9), cnt[0].item(), limw))
 
 
 if __name__ == "__main__":

@@ -217,10 +217,12 @@ __device__ __forceinline__ void inv21_mul(const float *inv21, const float *v, fl
 // ---------------------------------------------------------------- LDS layout (per team)
 constexpr int NJMAX = TL - 7;   // 25 hinge joints at most (26 bodies + 6 base dofs = 32 lanes)
 struct TeamLds {
-  float cst[28][TL];        // this team's body constants, re-read every substep (not carried in VGPRs) 3584 B
+  float minv[NJMAX][TL];    // [j-1][dof lane]: column j of M^-1 (motor / limit row responses)       3200 B
   float aba[TL][28];        // tip-to-base staging: Ia (21) + pa (6) per body; afterwards reused as the
                             // broadcast stage for the M^-1 columns and the contact blocks        3584 B
   float4 crow[MAXC * 3];    // contact rows: {rhs, 1/diag, K1, K2}, read back as a team broadcast   768 B
+  float clam[MAXC * 3];     // contact impulses (every lane computes them; parked here between sweeps) 192 B
+  float sink[TL];           // store target of the lanes that must not write clam (keeps the row branch-free)
 };
 static_assert(sizeof(float) * TL * 28 >= sizeof(float) * MAXC * 52, "contact stage must fit the aba region");
 
@@ -272,27 +274,19 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
   for (int k = 0; k < MAXCH; k++) child[k] = is_body ? M->child[k][lane] : -1;
   const unsigned desc_mask = M->desc_mask[lane];
   float axis[3], jpos[3], jrot[9], comb[3], inb[6], sph[4];
-  {
-    // one global read per launch; every substep re-reads the 28 floats from LDS
-#pragma unroll
-    for (int c = 0; c < 3; c++) { lds.cst[c][lane] = M->axis[c][lane]; lds.cst[3 + c][lane] = M->jpos[c][lane]; lds.cst[6 + c][lane] = M->com[c][lane]; }
-#pragma unroll
-    for (int c = 0; c < 9; c++) lds.cst[9 + c][lane] = M->jrot[c][lane];
-#pragma unroll
-    for (int c = 0; c < 6; c++) lds.cst[18 + c][lane] = M->inertia[c][lane];
-#pragma unroll
-    for (int c = 0; c < 4; c++) lds.cst[24 + c][lane] = M->sphere[c][lane];
-  }
-  __syncthreads();
   auto load_body_constants = [&]() {
+    // re-read at the top of every substep from the L2-resident model (opaque pointer: the compiler
+    // must not hoist these loads and then spill 28 registers across the solver loop)
+    const TrexDeviceModel *Mi = M;
+    asm volatile("" : "+s"(Mi));
 #pragma unroll
-    for (int c = 0; c < 3; c++) { axis[c] = lds.cst[c][lane]; jpos[c] = lds.cst[3 + c][lane]; comb[c] = lds.cst[6 + c][lane]; }
+    for (int c = 0; c < 3; c++) { axis[c] = Mi->axis[c][lane]; jpos[c] = Mi->jpos[c][lane]; comb[c] = Mi->com[c][lane]; }
 #pragma unroll
-    for (int c = 0; c < 9; c++) jrot[c] = lds.cst[9 + c][lane];
+    for (int c = 0; c < 9; c++) jrot[c] = Mi->jrot[c][lane];
 #pragma unroll
-    for (int c = 0; c < 6; c++) inb[c] = lds.cst[18 + c][lane];
+    for (int c = 0; c < 6; c++) inb[c] = Mi->inertia[c][lane];
 #pragma unroll
-    for (int c = 0; c < 4; c++) sph[c] = lds.cst[24 + c][lane];
+    for (int c = 0; c < 4; c++) sph[c] = Mi->sphere[c][lane];
   };
   const float q_lo = M->lower[lane], q_hi = M->upper[lane], jdamp = M->damp[lane];
   const int hull_v0 = M->hull_start[lane < nb ? lane : nb], hull_v1 = M->hull_start[lane < nb ? lane + 1 : nb];
@@ -637,11 +631,10 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       for (int k = 0; k < 6; k++) o[12 + k] = g[k];
     }
     __syncthreads();
-    float mcol[NJMAX];
     float mdiag = 1.f;
 #pragma unroll
     for (int j = 1; j <= NJMAX; j++) {
-      mcol[j - 1] = 0.f;
+      if (j >= nb) lds.minv[j - 1][lane] = 0.f;
       if (j < nb) {
         const float *o = lds.aba[j];
         int ca[MAXD];
@@ -651,7 +644,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
 #pragma unroll
         for (int k = 0; k < 6; k++) z0[k] = o[12 + k];
         const float w = response(ca, zc, z0);
-        mcol[j - 1] = w;
+        lds.minv[j - 1][lane] = w;
         if (lane == j) mdiag = w;
       }
     }
@@ -916,13 +909,21 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       }
     }
     __syncthreads();
+    if (lane < MAXC) { lds.clam[3 * lane] = 0.f; lds.clam[3 * lane + 1] = 0.f; lds.clam[3 * lane + 2] = 0.f; }
+    __syncthreads();
     STAMP(11);
-    float lam[MAXC][3];
-#pragma unroll
-    for (int c = 0; c < MAXC; c++) { lam[c][0] = 0.f; lam[c][1] = 0.f; lam[c][2] = 0.f; }
     float dv = 0.f;
     const unsigned lim_wave = lim_mask | (unsigned)__shfl_xor((int)lim_mask, 32);
+#if TREX_STAMPS
+    unsigned long long acc_joint = 0, acc_contact = 0;
+#endif
     for (int it = 0; it < iters; it++) {
+#if TREX_STAMPS
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       if (lim_wave) {   // some joint of this wave sits on a stop: all 25 limit rows, branch-free
 #pragma unroll
         for (int j = 1; j <= NJMAX; j++) {
@@ -930,7 +931,8 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
           float delta = (nl - lim_lam) * lim_dir;   // lim_dir == 0 on lanes without an active row
           if (lane == j) lim_lam = nl;
           delta = tbcast(delta, j);
-          dv += delta * mcol[j - 1];
+          dv += delta * lds.minv[j - 1][lane];
+          if (j % 5 == 0) __builtin_amdgcn_sched_barrier(0);
         }
       }
 #pragma unroll
@@ -939,41 +941,61 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
         float delta = nl - mot_lam;
         if (lane == j) mot_lam = nl;
         delta = tbcast(delta, j);
-        dv += delta * mcol[j - 1];
+        dv += delta * lds.minv[j - 1][lane];
+        if (j % 5 == 0) __builtin_amdgcn_sched_barrier(0);   // prefetch window of 5 columns
       }
+#if TREX_STAMPS
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_sched_barrier(0);
+      acc_joint += ts1 - ts0;
+#endif
 #pragma unroll
       for (int g = 0; g < MAXC / GP; g++) {
         if (GP * g < ncw) {
           const int r0 = GR * g;
           float4 qa = lds.crow[r0], qb = lds.crow[r0 + 1];
+          float la = lds.clam[r0], lb = lds.clam[r0 + 1];
           float pa = tsum(Jc[r0 / 3][0] * dv), pb = tsum(Jc[r0 / 3][1] * dv);
+          float lam_n = 0.f;
 #pragma unroll
           for (int k = 0; k < GR; k++) {
             const int r = r0 + k, c = r / 3, a = r % 3;
             float4 qc = make_float4(0.f, 0.f, 0.f, 0.f);
-            float pc = 0.f;
+            float pc = 0.f, lc = 0.f;
             if (k + 2 < GR) {   // start row r+2 from the dv of this moment (rows r, r+1 still missing)
               qc = lds.crow[r + 2];
+              lc = lds.clam[r + 2];
               pc = tsum(Jc[(r + 2) / 3][(r + 2) % 3] * dv);
             }
-            const float hi = (a == 0) ? 1.0e30f : mu * lam[c][0];
+            const float hi = (a == 0) ? 1.0e30f : mu * lam_n;
             const float lo = (a == 0) ? 0.f : -hi;
-            const float nl = __builtin_amdgcn_fmed3f(lam[c][a] + (qa.x - pa * qa.y), lo, hi);
-            const float d = nl - lam[c][a];
-            lam[c][a] = nl;
+            const float nl = __builtin_amdgcn_fmed3f(la + (qa.x - pa * qa.y), lo, hi);
+            const float d = nl - la;
+            if (a == 0) lam_n = nl;
+            *((lane == 0) ? &lds.clam[r] : &lds.sink[lane]) = nl;   // one ds_write, no exec branch
             dv += d * Wc[c][a];
             pb += d * qb.z;                    // K1 of row r+1
             if (k + 2 < GR) pc += d * qc.w;    // K2 of row r+2
-            pa = pb; qa = qb; pb = pc; qb = qc;
+            pa = pb; qa = qb; la = lb; pb = pc; qb = qc; lb = lc;
+            // bound the scheduler's window: without this it hoists a whole group's reductions and
+            // LDS reads, the live ranges explode and the loop spills to scratch (measured 44 ops)
+            if (a == 2) __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
     }
+#if TREX_STAMPS
+    if (args.debug && blockIdx.x == 0 && threadIdx.x == 0) {
+      args.debug[3000 + 16 * sub + 14] = (float)acc_joint;
+      args.debug[3000 + 16 * sub + 15] = (float)lim_wave;
+    }
+#endif
+    __syncthreads();
     STAMP(12);
     if (lane < nc) {  // hand the owner lane its impulses (diagnostics, contact statistics)
-#pragma unroll
-      for (int c = 0; c < MAXC; c++)
-        if (lane == c) { c_lam[0] = lam[c][0]; c_lam[1] = lam[c][1]; c_lam[2] = lam[c][2]; }
+      c_lam[0] = lds.clam[3 * lane]; c_lam[1] = lds.clam[3 * lane + 1]; c_lam[2] = lds.clam[3 * lane + 2];
     }
 
     if (args.debug && blockIdx.x == 0 && team == 0) {
@@ -982,7 +1004,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       if (lane < 6) D[32 + lane] = a0[lane];
       if (lane == 0) { D[128] = (float)nc; D[129] = (float)lim_mask; }
 #pragma unroll
-      for (int j = 1; j <= NJMAX; j++) D[160 + 32 * (j - 1) + lane] = mcol[j - 1];
+      for (int j = 1; j <= NJMAX; j++) D[160 + 32 * (j - 1) + lane] = lds.minv[j - 1][lane];
       if (lane < nc) {
         float *C = D + 960 + lane * 16;
         C[0] = (float)cbody; C[1] = cx[0]; C[2] = cx[1]; C[3] = cx[2]; C[4] = cdist;
