@@ -220,9 +220,6 @@ struct TeamLds {
   float minv[NJMAX][TL];    // [j-1][dof lane]: column j of M^-1 (motor / limit row responses)       3200 B
   float aba[TL][28];        // tip-to-base staging: Ia (21) + pa (6) per body; afterwards reused as the
                             // broadcast stage for the M^-1 columns and the contact blocks        3584 B
-  float4 crow[MAXC * 3];    // contact rows: {rhs, 1/diag, K1, K2}, read back as a team broadcast   768 B
-  float clam[MAXC * 3];     // contact impulses (every lane computes them; parked here between sweeps) 192 B
-  float sink[TL];           // store target of the lanes that must not write clam (keeps the row branch-free)
 };
 static_assert(sizeof(float) * TL * 28 >= sizeof(float) * MAXC * 52, "contact stage must fit the aba region");
 
@@ -891,26 +888,24 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
     // early from the dv of that moment and completed with the scalar couplings K1_r = J_r.W_(r-1),
     // K2_r = J_r.W_(r-2) once those rows' impulse changes are known - identical arithmetic up to
     // rounding (J.(dv + d W) = J.dv + d (J.W)), but the dependent chain per row shrinks from
-    // reduce+solve (13 ops) to correct+solve (6 ops). Rows are processed in groups of 4 points
-    // (one basic block each, so the scheduler can overlap the two chains).
+    // reduce+solve to correct+solve. Row constants {rhs, 1/diag, K1, K2, lambda} live in the
+    // registers of the point's OWNER lane (lane c for point c); the all-reduced J.dv is present on
+    // every lane, the owner finishes the row and two v_readlane broadcast the impulse change.
+    // No LDS and no exec branch inside a row. Rows run in groups of 4 points (one basic block each).
     constexpr int GP = 4, GR = 3 * GP;
+    float c_k1[3] = {0.f, 0.f, 0.f}, c_k2[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < MAXC / GP; g++) {
       if (GP * g < ncw) {
 #pragma unroll
         for (int k = 0; k < GR; k++) {
           const int r = GR * g + k, c = r / 3, a = r % 3;
-          float k1 = 0.f, k2 = 0.f;
-          if (k >= 1) k1 = tsum(Jc[c][a] * Wc[(r - 1) / 3][(r - 1) % 3]);
-          if (k >= 2) k2 = tsum(Jc[c][a] * Wc[(r - 2) / 3][(r - 2) % 3]);
-          const bool own = lane == c && c < nc;
-          if (lane == c) lds.crow[r] = own ? make_float4(c_rhs[a], c_inv[a], k1, k2) : make_float4(0.f, 0.f, 0.f, 0.f);
+          if (k >= 1) { const float t = tsum(Jc[c][a] * Wc[(r - 1) / 3][(r - 1) % 3]); if (lane == c) c_k1[a] = t; }
+          if (k >= 2) { const float t = tsum(Jc[c][a] * Wc[(r - 2) / 3][(r - 2) % 3]); if (lane == c) c_k2[a] = t; }
         }
       }
     }
-    __syncthreads();
-    if (lane < MAXC) { lds.clam[3 * lane] = 0.f; lds.clam[3 * lane + 1] = 0.f; lds.clam[3 * lane + 2] = 0.f; }
-    __syncthreads();
+    c_lam[0] = c_lam[1] = c_lam[2] = 0.f;
     STAMP(11);
     float dv = 0.f;
     const unsigned lim_wave = lim_mask | (unsigned)__shfl_xor((int)lim_mask, 32);
@@ -936,7 +931,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
         }
       }
 #pragma unroll
-      for (int j = 1; j <= NJMAX; j++) {   // joints beyond nb have mot_hi = 0 and mcol = 0
+      for (int j = 1; j <= NJMAX; j++) {   // joints beyond nb have mot_hi = 0 and a zero column
         const float nl = __builtin_amdgcn_fmed3f(mot_lam + (mot_rhs - dv * inv_mdiag), -mot_hi, mot_hi);
         float delta = nl - mot_lam;
         if (lane == j) mot_lam = nl;
@@ -955,33 +950,24 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       for (int g = 0; g < MAXC / GP; g++) {
         if (GP * g < ncw) {
           const int r0 = GR * g;
-          float4 qa = lds.crow[r0], qb = lds.crow[r0 + 1];
-          float la = lds.clam[r0], lb = lds.clam[r0 + 1];
           float pa = tsum(Jc[r0 / 3][0] * dv), pb = tsum(Jc[r0 / 3][1] * dv);
-          float lam_n = 0.f;
 #pragma unroll
           for (int k = 0; k < GR; k++) {
             const int r = r0 + k, c = r / 3, a = r % 3;
-            float4 qc = make_float4(0.f, 0.f, 0.f, 0.f);
-            float pc = 0.f, lc = 0.f;
-            if (k + 2 < GR) {   // start row r+2 from the dv of this moment (rows r, r+1 still missing)
-              qc = lds.crow[r + 2];
-              lc = lds.clam[r + 2];
-              pc = tsum(Jc[(r + 2) / 3][(r + 2) % 3] * dv);
-            }
-            const float hi = (a == 0) ? 1.0e30f : mu * lam_n;
+            float pc = 0.f;
+            if (k + 2 < GR) pc = tsum(Jc[(r + 2) / 3][(r + 2) % 3] * dv);   // rows r, r+1 still missing
+            // owner lane c: finish row r (other lanes compute on their own, unused, values)
+            const float hi = (a == 0) ? 1.0e30f : mu * c_lam[0];
             const float lo = (a == 0) ? 0.f : -hi;
-            const float nl = __builtin_amdgcn_fmed3f(la + (qa.x - pa * qa.y), lo, hi);
-            const float d = nl - la;
-            if (a == 0) lam_n = nl;
-            *((lane == 0) ? &lds.clam[r] : &lds.sink[lane]) = nl;   // one ds_write, no exec branch
+            const float nl = __builtin_amdgcn_fmed3f(c_lam[a] + (c_rhs[a] - pa * c_inv[a]), lo, hi);
+            float d = nl - c_lam[a];
+            if (lane == c) c_lam[a] = nl;
+            d = tbcast(d, c);
             dv += d * Wc[c][a];
-            pb += d * qb.z;                    // K1 of row r+1
-            if (k + 2 < GR) pc += d * qc.w;    // K2 of row r+2
-            pa = pb; qa = qb; la = lb; pb = pc; qb = qc; lb = lc;
-            // bound the scheduler's window: without this it hoists a whole group's reductions and
-            // LDS reads, the live ranges explode and the loop spills to scratch (measured 44 ops)
-            if (a == 2) __builtin_amdgcn_sched_barrier(0);
+            pb += d * c_k1[(a + 1) % 3];                   // K1 of row r+1, exact on that row's owner
+            if (k + 2 < GR) pc += d * c_k2[(a + 2) % 3];   // K2 of row r+2, exact on that row's owner
+            pa = pb; pb = pc;
+            if (a == 2) __builtin_amdgcn_sched_barrier(0);  // bound live ranges: one point per window
           }
         }
       }
@@ -994,9 +980,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
 #endif
     __syncthreads();
     STAMP(12);
-    if (lane < nc) {  // hand the owner lane its impulses (diagnostics, contact statistics)
-      c_lam[0] = lds.clam[3 * lane]; c_lam[1] = lds.clam[3 * lane + 1]; c_lam[2] = lds.clam[3 * lane + 2];
-    }
+
 
     if (args.debug && blockIdx.x == 0 && team == 0) {
       float *D = args.debug;
