@@ -72,6 +72,33 @@ __device__ __forceinline__ float tsum(float v) {
   const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+__device__ __forceinline__ float tminf(float v) {
+  v = fminf(v, dpp_mov<0xB1>(v));
+  v = fminf(v, dpp_mov<0x4E>(v));
+  v = fminf(v, dpp_mov<0x141>(v));
+  v = fminf(v, dpp_mov<0x140>(v));
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return fminf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+__device__ __forceinline__ int tmini(int v) {   // non-negative values
+  v = min(v, dpp_mov_i<0xB1>(v));
+  v = min(v, dpp_mov_i<0x4E>(v));
+  v = min(v, dpp_mov_i<0x141>(v));
+  v = min(v, dpp_mov_i<0x140>(v));
+  const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+  return min((int)r[0], (int)r[1]);
+}
+// team arg-max with ties to the lowest index: returns the winning (score, index) on every lane
+__device__ __forceinline__ void targmax(float &score, int &index) {
+  const float best = -tminf(-score);
+  index = tmini(score == best ? index : 0x7fffffff);
+  score = best;
+}
 // value held by team lane `src` (src WAVE-uniform), through SGPRs: two v_readlane + one select
 __device__ __forceinline__ float tbcast(float v, int src) {
   const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
@@ -667,6 +694,10 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
 
     STAMP(7);
     // ---- contact generation: hull vertices against z <= floor_z
+    // Pass A walks the near bodies once: it finds whether a body has any vertex inside the margin and,
+    // in the same sweep, its DEEPEST such vertex (= the first point the selection rule keeps), parked in
+    // lane b's registers. Pass B revisits a body's vertices only when more than one point per body is
+    // kept (K >= 2, i.e. fewer than 8 bodies touch).
     int nc = 0;
     int cbody = 0;
     float cx[3] = {0.f, 0.f, 0.f}, cdist = 0.f;
@@ -676,19 +707,36 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       const bool near = is_body && hull_v1 > hull_v0 && (pos[2] + r[2] + sc[2] - sph[3] - floor_z < margin);
       unsigned near_mask = tballot(near);
       unsigned active_mask = 0u;
+      float a_x[3] = {0.f, 0.f, 0.f}, a_d = 0.f;   // lane b: deepest candidate of body b
+      int a_v = -1;
       while (wave_any(near_mask != 0u)) {
         const bool valid = near_mask != 0u;
         const int b = valid ? (__ffs(near_mask) - 1) : 0;
         near_mask &= near_mask - 1u;
-        const float Rz0 = tshfl(R[6], b), Rz1 = tshfl(R[7], b), Rz2 = tshfl(R[8], b);
-        const float z0 = pos[2] + tshfl(r[2], b) - floor_z;
-        const int v0 = M->hull_start[b], v1 = M->hull_start[b + 1];
-        bool any = false;
+        float Rb[9], rb[3];
+#pragma unroll
+        for (int c = 0; c < 9; c++) Rb[c] = tshfl(R[c], b);
+#pragma unroll
+        for (int c = 0; c < 3; c++) rb[c] = tshfl(r[c], b);
+        const int v0 = tshfl(hull_v0, b), v1 = tshfl(hull_v1, b);
+        float bs = -3.0e38f, bx[3] = {0.f, 0.f, 0.f};
+        int bi = 0x7fffffff;
         for (int v = v0 + lane; v < v1; v += TL) {
           const float4 h = args.arr.hull[v];
-          any |= (z0 + Rz0 * h.x + Rz1 * h.y + Rz2 * h.z) < margin;
+          const float hv[3] = {h.x, h.y, h.z};
+          float w[3];
+          matvec3(Rb, hv, w);
+          const float dd = pos[2] + rb[2] + w[2] - floor_z;
+          if (dd < margin && -dd > bs) { bs = -dd; bi = v; bx[0] = rb[0] + w[0]; bx[1] = rb[1] + w[1]; bx[2] = rb[2] + w[2]; }
         }
-        if (valid && tballot(any) != 0u) active_mask |= 1u << b;
+        const int mine = bi;
+        targmax(bs, bi);
+        if (valid && bi != 0x7fffffff) {
+          active_mask |= 1u << b;
+          const int win = __ffs(tballot(mine == bi)) - 1;   // the lane that holds the winner's position
+          const float wx = tshfl(bx[0], win), wy = tshfl(bx[1], win), wz = tshfl(bx[2], win);
+          if (lane == b) { a_x[0] = wx; a_x[1] = wy; a_x[2] = wz; a_d = -bs; a_v = bi; }
+        }
       }
       const int n_active = __popc(active_mask);
       int K = n_active > 0 ? maxc / n_active : 0;
@@ -697,64 +745,62 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
         const bool valid = active_mask != 0u;
         const int b = valid ? (__ffs(active_mask) - 1) : 0;
         active_mask &= active_mask - 1u;
-        float Rb[9], rb[3];
-#pragma unroll
-        for (int c = 0; c < 9; c++) Rb[c] = tshfl(R[c], b);
-#pragma unroll
-        for (int c = 0; c < 3; c++) rb[c] = tshfl(r[c], b);
-        const int v0 = M->hull_start[b], v1 = M->hull_start[b + 1];
         int sel[4] = {-1, -1, -1, -1};
         float px[4][3], pd[4];
-        int nsel = 0;
-        bool stop = !valid;
+        sel[0] = tshfl(a_v, b);
 #pragma unroll
-        for (int pass = 0; pass < 4; pass++) {
-          float bs = -3.0e38f;
-          int bi = 0x7fffffff;
-          float ex = 0.f, ey = 0.f, flip = 1.f;
-          if (pass >= 2) { ex = px[1][0] - px[0][0]; ey = px[1][1] - px[0][1]; }
-          if (pass == 3) {
-            const float c3 = ex * (px[2][1] - px[0][1]) - ey * (px[2][0] - px[0][0]);
-            flip = c3 > 0.f ? -1.f : 1.f;
-          }
-          for (int v = v0 + lane; v < v1; v += TL) {
-            const float4 h = args.arr.hull[v];
-            const float hv[3] = {h.x, h.y, h.z};
-            float w[3];
-            matvec3(Rb, hv, w);
-            const float x0 = rb[0] + w[0], x1 = rb[1] + w[1], x2 = rb[2] + w[2];
-            const float dd = pos[2] + x2 - floor_z;
-            if (!(dd < margin)) continue;
-            if (v == sel[0] || v == sel[1] || v == sel[2]) continue;
-            float score;
-            if (pass == 0) score = -dd;
-            else {
+        for (int c = 0; c < 3; c++) px[0][c] = tshfl(a_x[c], b);
+        pd[0] = tshfl(a_d, b);
+        int nsel = valid ? 1 : 0;
+        bool stop = !valid || K < 2;
+        if (wave_any(!stop)) {
+          float Rb[9], rb[3];
+#pragma unroll
+          for (int c = 0; c < 9; c++) Rb[c] = tshfl(R[c], b);
+#pragma unroll
+          for (int c = 0; c < 3; c++) rb[c] = tshfl(r[c], b);
+          const int v0 = tshfl(hull_v0, b), v1 = tshfl(hull_v1, b);
+#pragma unroll
+          for (int pass = 1; pass < 4; pass++) {
+            if (!wave_any(!stop)) break;
+            float bs = -3.0e38f;
+            int bi = 0x7fffffff;
+            float ex = 0.f, ey = 0.f, flip = 1.f;
+            if (pass >= 2) { ex = px[1][0] - px[0][0]; ey = px[1][1] - px[0][1]; }
+            if (pass == 3) {
+              const float c3 = ex * (px[2][1] - px[0][1]) - ey * (px[2][0] - px[0][0]);
+              flip = c3 > 0.f ? -1.f : 1.f;
+            }
+            float bx[3] = {0.f, 0.f, 0.f};
+            for (int v = v0 + lane; v < v1; v += TL) {
+              const float4 h = args.arr.hull[v];
+              const float hv[3] = {h.x, h.y, h.z};
+              float w[3];
+              matvec3(Rb, hv, w);
+              const float x0 = rb[0] + w[0], x1 = rb[1] + w[1], x2 = rb[2] + w[2];
+              const float dd = pos[2] + x2 - floor_z;
+              if (!(dd < margin)) continue;
+              if (v == sel[0] || v == sel[1] || v == sel[2]) continue;
               const float dx = x0 - px[0][0], dy = x1 - px[0][1];
+              float score;
               if (pass == 1) score = dx * dx + dy * dy;
               else {
                 const float cr = ex * dy - ey * dx;
                 score = (pass == 2) ? fabsf(cr) : flip * cr;
               }
+              if (score > bs) { bs = score; bi = v; bx[0] = x0; bx[1] = x1; bx[2] = x2; }
             }
-            if (score > bs) { bs = score; bi = v; }
-          }
-#pragma unroll
-          for (int m = TL / 2; m >= 1; m >>= 1) {
-            const float os = __shfl_xor(bs, m, TL);
-            const int oi = __shfl_xor(bi, m, TL);
-            if (os > bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
-          }
-          if (pass >= K || bi == 0x7fffffff || (pass >= 1 && !(bs > 0.f))) stop = true;
-          if (!stop) {
-            const float4 h = args.arr.hull[bi];
-            const float hv[3] = {h.x, h.y, h.z};
-            float w[3];
-            matvec3(Rb, hv, w);
-            sel[pass] = bi;
-#pragma unroll
-            for (int c = 0; c < 3; c++) px[pass][c] = rb[c] + w[c];
-            pd[pass] = pos[2] + px[pass][2] - floor_z;
-            nsel = pass + 1;
+            const int mine = bi;
+            targmax(bs, bi);
+            if (pass >= K || bi == 0x7fffffff || !(bs > 0.f)) stop = true;
+            const int win = __ffs(tballot(mine == bi && bi != 0x7fffffff)) - 1;
+            const float wx = tshfl(bx[0], win < 0 ? 0 : win), wy = tshfl(bx[1], win < 0 ? 0 : win), wz = tshfl(bx[2], win < 0 ? 0 : win);
+            if (!stop) {
+              sel[pass] = bi;
+              px[pass][0] = wx; px[pass][1] = wy; px[pass][2] = wz;
+              pd[pass] = pos[2] + wz - floor_z;
+              nsel = pass + 1;
+            }
           }
         }
 #pragma unroll
