@@ -10,10 +10,12 @@
 //     26 bodies and 25 + 6 = 31 degrees of freedom, so a team's lanes are (a) the bodies 0..25 for the
 //     tree sweeps and (b) the dofs for the constraint solve: lanes 1..25 = joint of that body,
 //     lanes 26..31 = base angular xyz / linear xyz.  No inter-wave synchronisation exists.
-//   * every spatial quantity of an env lives in ONE frame (world axes, origin at the base frame
-//     origin), so parent->child sweeps need no frame transforms: base-to-tip passes move 6..12
-//     registers per level with wavefront shuffles (ds_bpermute within the half), the tip-to-base
-//     articulated-inertia pass stages 27 floats per body through LDS.
+//   * every spatial quantity is expressed in WORLD-ALIGNED axes about the body's OWN frame origin
+//     (the joint axis passes through it). Parent<->child sweeps therefore need no rotations - only
+//     the translation by the joint offset d - and, unlike a single common origin, no quantity is a
+//     difference of m*r^2-sized terms (f32-safe: D_i = a.(I a) directly). Base-to-tip passes move
+//     6..12 registers per level with wavefront shuffles (ds_bpermute within the half), the
+//     tip-to-base articulated-inertia pass stages 27 floats per body through LDS.
 //   * M^-1 is never formed by repeated sweeps: the ABA factorisation M^-1 = A^T B A is kept
 //     DISTRIBUTED (lane j holds column j of A: <= 6 ancestor entries + 6 base entries), which makes
 //     every constraint row's response vector a handful of FMAs.
@@ -361,12 +363,12 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
   if (maxc > MAXC) maxc = MAXC;
 
   // kinematic quantities of this lane's body
-  float R[9], r[3], S[6];
+  float R[9], r[3], dpar[3] = {0.f, 0.f, 0.f}, S[6];   // dpar = r - r(parent), world axes
   int stat_nc = 0;
   float stat_imp = 0.f;
 
   // FK: world rotation R and origin r (relative to the base origin) of every body; joint motion
-  // subspace S = [a; r x a].  (base-to-tip, one level per step, parent data via shuffles)
+  // subspace about the body's own origin S = [a; 0].  (base-to-tip, parent data via shuffles)
   auto forward_kinematics = [&]() {
     float Rl[9];
     {
@@ -390,20 +392,20 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
         matmul3(pR, Rl, R);
         matvec3(pR, jpos, o);
 #pragma unroll
-        for (int c = 0; c < 3; c++) r[c] = pr[c] + o[c];
+        for (int c = 0; c < 3; c++) { dpar[c] = o[c]; r[c] = pr[c] + o[c]; }
       }
     }
     float a[3];
     matvec3(R, axis, a);
     S[0] = a[0]; S[1] = a[1]; S[2] = a[2];
-    cross3(r, a, S + 3);
+    S[3] = S[4] = S[5] = 0.f;
     if (!is_joint) {
 #pragma unroll
       for (int c = 0; c < 6; c++) S[c] = 0.f;
     }
   };
 
-  // spatial velocity of every body for base twist (w, v) and joint rates rate (per joint lane)
+  // spatial velocity of every body ABOUT ITS OWN ORIGIN for base twist (w, v) and joint rates
   auto body_velocities = [&](const float *w, const float *v, float rate, float *vel) {
 #pragma unroll
     for (int c = 0; c < 3; c++) { vel[c] = w[c]; vel[3 + c] = v[c]; }
@@ -412,8 +414,10 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
 #pragma unroll
       for (int c = 0; c < 6; c++) pv[c] = tshfl(vel[c], psrc);
       if (depth == d) {
+        float wxd[3];
+        cross3(pv, dpar, wxd);   // velocity of the parent-body point at this body's origin
 #pragma unroll
-        for (int c = 0; c < 6; c++) vel[c] = pv[c] + S[c] * rate;
+        for (int c = 0; c < 3; c++) { vel[c] = pv[c] + S[c] * rate; vel[3 + c] = pv[3 + c] + wxd[c]; }
       }
     }
   };
@@ -429,13 +433,10 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
     body_velocities(bw, bv, qd, vel);
 
     STAMP(0);
-    // ---- rigid-body spatial inertia about O, bias force, velocity-product acceleration
-    float comw[3], Icw[6];
+    // ---- rigid-body spatial inertia about the body origin, bias force, velocity-product acceleration
+    float comw[3], Icw[6];   // comw = COM offset from the body origin, world axes
     {
-      float c[3];
-      matvec3(R, comb, c);
-#pragma unroll
-      for (int k = 0; k < 3; k++) comw[k] = r[k] + c[k];
+      matvec3(R, comb, comw);
       // Ic_world = R Ib R^T (symmetric)
       float t[9];
       const float Ib[9] = {inb[0], inb[1], inb[2], inb[1], inb[3], inb[4], inb[2], inb[4], inb[5]};
@@ -525,13 +526,54 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
         const float uc = dot6(U, cv);
         Sym6 Ia = IA;
         sym6_rank1_sub(Ia, U, invD);
+        float pa[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) pa[k] = pA[k] + Ic[k] + U[k] * (u - uc) * invD;
+        // shift both to the parent's origin (this origin = parent origin + dpar):
+        //   B' = B + [d]x C,  A' = A - B [d]x + [d]x B'^T,  C' = C,  n' = n + d x f
+        {
+          const int sidx[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+          float Bn[9], BD[9], DBt[9];
+#pragma unroll
+          for (int j = 0; j < 3; j++) {   // column j of [d]x C = d x (column j of C)
+            const float cj[3] = {Ia.C[sidx[0][j]], Ia.C[sidx[1][j]], Ia.C[sidx[2][j]]};
+            float t[3];
+            cross3(dpar, cj, t);
+#pragma unroll
+            for (int i = 0; i < 3; i++) Bn[3 * i + j] = Ia.B[3 * i + j] + t[i];
+          }
+#pragma unroll
+          for (int i = 0; i < 3; i++) {   // row i of B [d]x = -(d x row i of B)
+            float t[3];
+            cross3(dpar, Ia.B + 3 * i, t);
+#pragma unroll
+            for (int j = 0; j < 3; j++) BD[3 * i + j] = -t[j];
+          }
+#pragma unroll
+          for (int j = 0; j < 3; j++) {   // column j of [d]x B'^T = d x (row j of B')
+            float t[3];
+            cross3(dpar, Bn + 3 * j, t);
+#pragma unroll
+            for (int i = 0; i < 3; i++) DBt[3 * i + j] = t[i];
+          }
+          const int ia6[6] = {0, 0, 0, 1, 1, 2}, ib6[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+          for (int k = 0; k < 6; k++) {   // symmetric part (exactly symmetric in exact arithmetic)
+            const int ij = 3 * ia6[k] + ib6[k], ji = 3 * ib6[k] + ia6[k];
+            Ia.A[k] += 0.5f * ((DBt[ij] - BD[ij]) + (DBt[ji] - BD[ji]));
+          }
+#pragma unroll
+          for (int k = 0; k < 9; k++) Ia.B[k] = Bn[k];
+          float dxf[3];
+          cross3(dpar, pa + 3, dxf);
+#pragma unroll
+          for (int k = 0; k < 3; k++) pa[k] += dxf[k];
+        }
         float *o = lds.aba[lane];
 #pragma unroll
-        for (int k = 0; k < 6; k++) { o[k] = Ia.A[k]; o[15 + k] = Ia.C[k]; }
+        for (int k = 0; k < 6; k++) { o[k] = Ia.A[k]; o[15 + k] = Ia.C[k]; o[21 + k] = pa[k]; }
 #pragma unroll
         for (int k = 0; k < 9; k++) o[6 + k] = Ia.B[k];
-#pragma unroll
-        for (int k = 0; k < 6; k++) o[21 + k] = pA[k] + Ic[k] + U[k] * (u - uc) * invD;
       }
       __syncthreads();
       if (depth == d - 1) {
@@ -575,6 +617,10 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
 #pragma unroll
         for (int k = 0; k < 6; k++) pa[k] = tshfl(acc[k], psrc);
         if (depth == d) {
+          float axd[3];
+          cross3(pa, dpar, axd);   // parent acceleration seen at this body's origin
+#pragma unroll
+          for (int k = 0; k < 3; k++) pa[3 + k] += axd[k];
 #pragma unroll
           for (int k = 0; k < 6; k++) pa[k] += cv[k];
           qdd = (u - dot6(U, pa)) * invD;
@@ -596,7 +642,8 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
     }
     float nqd = fminf(fmaxf(qd + qdd * dt, -vmax), vmax);
     float vg = is_joint ? nqd : 0.f;
-    // dof-lane motion subspace: joint lanes S, base dof lanes unit vectors
+    // dof-lane motion subspace about the dof's own origin: joint lanes S about r, base dof lanes unit
+    // vectors about O
     float Sd[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) {
@@ -610,26 +657,42 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
     //   Z[d-1]    = Aanc[d-1] / D(ancestor), g = I0inv * A0
     float Aanc[MAXD], Z[MAXD], A0[6], g[6];
     {
-      float p[6];
+      float p[6], po[3];   // force p about the point po (starts at this joint's origin, walks up)
 #pragma unroll
       for (int k = 0; k < 6; k++) p[k] = is_joint ? Ud[k] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; k++) po[k] = r[k];
 #pragma unroll
       for (int d = MAXD; d >= 1; d--) {
         Aanc[d - 1] = 0.f; Z[d - 1] = 0.f;
         if (d <= maxdepth) {
           const int a = anc[d - 1] < 0 ? 0 : anc[d - 1];
-          float Sa[6], Uda[6];
+          float aa[3], Uda[6], ra[3];
 #pragma unroll
-          for (int k = 0; k < 6; k++) { Sa[k] = tshfl(S[k], a); Uda[k] = tshfl(Ud[k], a); }
+          for (int k = 0; k < 3; k++) { aa[k] = tshfl(S[k], a); ra[k] = tshfl(r[k], a); }
+#pragma unroll
+          for (int k = 0; k < 6; k++) Uda[k] = tshfl(Ud[k], a);
           const float invDa = tshfl(invD, a);
           if (is_joint && depth == d) { Aanc[d - 1] = 1.f; Z[d - 1] = invD; }
           else if (is_joint && depth > d) {
-            const float ua = -dot6(Sa, p);
+            float dd[3], dxf[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { dd[k] = po[k] - ra[k]; po[k] = ra[k]; }
+            cross3(dd, p + 3, dxf);
+#pragma unroll
+            for (int k = 0; k < 3; k++) p[k] += dxf[k];
+            const float ua = -dot3(aa, p);
             Aanc[d - 1] = ua; Z[d - 1] = ua * invDa;
 #pragma unroll
             for (int k = 0; k < 6; k++) p[k] += Uda[k] * ua;
           }
         }
+      }
+      {
+        float dxf[3];
+        cross3(po, p + 3, dxf);   // on to the base origin O
+#pragma unroll
+        for (int k = 0; k < 3; k++) p[k] += dxf[k];
       }
 #pragma unroll
       for (int k = 0; k < 6; k++) A0[k] = is_joint ? -p[k] : ((is_base_dof && bdof == k) ? 1.f : 0.f);
@@ -829,10 +892,13 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       for (int k = 0; k < 6; k++) vb[k] = tshfl(nvel[k], cbody);
       float p[3][6], diag[3] = {0.f, 0.f, 0.f};
       const float dirs[3][3] = {{0.f, 0.f, 1.f}, {1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}};
+      float po[3], xrel[3];   // po: the point the forces p[a] refer to (body origin first, then up the chain)
+#pragma unroll
+      for (int k = 0; k < 3; k++) { po[k] = tshfl(r[k], cbody); xrel[k] = cx[k] - po[k]; }
 #pragma unroll
       for (int a = 0; a < 3; a++) {
         float xd[3];
-        cross3(cx, dirs[a], xd);
+        cross3(xrel, dirs[a], xd);
 #pragma unroll
         for (int k = 0; k < 3; k++) { p[a][k] = -xd[k]; p[a][3 + k] = -dirs[a][k]; }
       }
@@ -845,14 +911,23 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
           const int ab = tshfl(anc[d - 1], cbody);
           c_anc[d - 1] = has ? ab : -1;
           const int src = ab < 0 ? 0 : ab;
-          float Sa[6], Uda[6];
+          float aa[3], Uda[6], ra[3];
 #pragma unroll
-          for (int k = 0; k < 6; k++) { Sa[k] = tshfl(S[k], src); Uda[k] = tshfl(Ud[k], src); }
+          for (int k = 0; k < 3; k++) { aa[k] = tshfl(S[k], src); ra[k] = tshfl(r[k], src); }
+#pragma unroll
+          for (int k = 0; k < 6; k++) Uda[k] = tshfl(Ud[k], src);
           const float invDa = tshfl(invD, src);
           if (has && ab >= 0) {
+            float dd[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { dd[k] = po[k] - ra[k]; po[k] = ra[k]; }
 #pragma unroll
             for (int a = 0; a < 3; a++) {
-              const float ua = -dot6(Sa, p[a]);
+              float dxf[3];
+              cross3(dd, p[a] + 3, dxf);
+#pragma unroll
+              for (int k = 0; k < 3; k++) p[a][k] += dxf[k];
+              const float ua = -dot3(aa, p[a]);
               c_zc[a][d - 1] = ua * invDa;
               diag[a] += ua * ua * invDa;
 #pragma unroll
@@ -862,12 +937,15 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
         }
       }
       float pvel[3], wxx[3];
-      cross3(vb, cx, wxx);
+      cross3(vb, xrel, wxx);   // body velocity is about the body origin
 #pragma unroll
       for (int k = 0; k < 3; k++) pvel[k] = vb[3 + k] + wxx[k];
 #pragma unroll
       for (int a = 0; a < 3; a++) {
-        float rhs0[6];
+        float rhs0[6], dxf[3];
+        cross3(po, p[a] + 3, dxf);   // on to the base origin O
+#pragma unroll
+        for (int k = 0; k < 3; k++) p[a][k] += dxf[k];
 #pragma unroll
         for (int k = 0; k < 6; k++) rhs0[k] = -p[a][k];
         inv21_mul(I0inv, rhs0, c_z0[a]);
@@ -910,8 +988,10 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
         for (int d = 0; d < MAXD; d++) ca[d] = __float_as_int(o[d]);
         const float x[3] = {o[42], o[43], o[44]};
         const int b = __float_as_int(o[45]);
+        // point velocity per unit dof rate: Sd_lin + Sd_ang x (x - origin of this dof)
+        const float xo[3] = {x[0] - (is_joint ? r[0] : 0.f), x[1] - (is_joint ? r[1] : 0.f), x[2] - (is_joint ? r[2] : 0.f)};
         float wx[3];
-        cross3(Sd, x, wx);
+        cross3(Sd, xo, wx);
         const bool on = (c < nc) && ((desc_mask >> b) & 1u);
         Jc[c][0] = on ? Sd[5] + wx[2] : 0.f;
         Jc[c][1] = on ? Sd[3] + wx[0] : 0.f;
