@@ -179,7 +179,7 @@ def main():
                        **({"ABLATION_param_overrides": overrides} if overrides else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "trex_step_kernel<false>", "kernel_ms": kernel_ms,
+                         "kernel": "trex_step_kernel<false, false>", "kernel_ms": kernel_ms,
                          "alg_bytes_per_launch": alg,
                          "note": "latency/VALU-bound by construction (serial PGS); HBM fraction reported as "
                                  "BASELINE asks, see DESIGN.md for the instruction-issue roofline"},

@@ -6,11 +6,12 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
 
 
 def load(d):
-    f = glob.glob(d + "/runc/*_counter_collection.csv")[0]
+    f = max(glob.glob(d + "/runc/*_counter_collection.csv"), key=os.path.getmtime)
     out = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         out[r["Kernel_Name"]].append(float(r["Counter_Value"]))
@@ -19,14 +20,14 @@ def load(d):
 
 def main():
     src, tag, timed = sys.argv[1], sys.argv[2], int(sys.argv[3])
-    res, lines = {}, ["# HBM traffic of `trex_step_kernel<false>` from PMC counters (%s)" % tag, "",
+    res, lines = {}, ["# HBM traffic of `trex_step_kernel<false, false>` from PMC counters (%s)" % tag, "",
                       "separate passes `rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --steps %d --warmup 30`;" % timed,
                       "calibration `profiles/tools/pmc_calib.hip` (1 GiB dword-per-lane copy) under the same counters.", ""]
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         b, k = load("%s/bench_%s" % (src, c)), load("%s/calib_%s" % (src, c))
         cal = [v for n, v in k.items() if "calib_copy_dword" in n][0]
         factor = (1 << 20) / (sum(cal) / len(cal))          # true KiB / counted KiB
-        step = [v for n, v in b.items() if "trex_step_kernel<false>" in n][0][-timed:]
+        step = [v for n, v in b.items() if "trex_step_kernel<false, false>" in n][0][-timed:]
         raw = sum(step) / len(step)
         res[c] = raw * 1024 * factor
         lines.append("* %s: calibration counts %.0f KiB for 1048576 KiB -> factor %.3f; step kernel raw %.0f KiB/launch -> **%.1f MB/launch**"

@@ -12,8 +12,8 @@ import sys
 def main():
     prof_dir, out_md, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
     bench_json = sys.argv[4] if len(sys.argv) > 4 else None
-    stats = glob.glob(os.path.join(prof_dir, "**", "*_kernel_stats.csv"), recursive=True)[0]
-    trace = glob.glob(os.path.join(prof_dir, "**", "*_kernel_trace.csv"), recursive=True)[0]
+    stats = max(glob.glob(os.path.join(prof_dir, "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+    trace = max(glob.glob(os.path.join(prof_dir, "**", "*_kernel_trace.csv"), recursive=True), key=os.path.getmtime)
     rows = list(csv.DictReader(open(stats)))
     lines = ["# rocprofv3 --kernel-trace --stats summary", "",
              "command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps %d ...`" % steps, "",
@@ -23,11 +23,11 @@ def main():
         lines.append("| %s | %s | %.2f | %.1f | %s | %.1f | %.1f |" % (
             name, r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, r["Percentage"],
             float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
-    t = [r for r in csv.DictReader(open(trace)) if "trex_step_kernel<false>" in r["Kernel_Name"]]
+    t = [r for r in csv.DictReader(open(trace)) if "trex_step_kernel<false, false>" in r["Kernel_Name"]]
     t.sort(key=lambda r: int(r["Start_Timestamp"]))
     d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in t]
     timed = d[-steps:]
-    lines += ["", "step kernel `trex_step_kernel<false>`: %d dispatches; timed region (last %d): avg %.3f ms, min %.3f, max %.3f"
+    lines += ["", "step kernel `trex_step_kernel<false, false>`: %d dispatches; timed region (last %d): avg %.3f ms, min %.3f, max %.3f"
               % (len(d), len(timed), sum(timed) / len(timed) / 1e6, min(timed) / 1e6, max(timed) / 1e6)]
     r0 = t[-1]
     keys = [k for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size") if k in r0]

@@ -46,7 +46,7 @@
     __builtin_amdgcn_sched_barrier(0);                                                    \
     const unsigned long long _t = __builtin_amdgcn_s_memtime();                           \
     __builtin_amdgcn_s_waitcnt(0xC07F);                                                   \
-    if (args.debug && blockIdx.x == 0 && threadIdx.x == 0) args.debug[3000 + 16 * sub + (i)] = (float)(_t - stamp_last); \
+    if (DEBUG && args.debug && blockIdx.x == 0 && threadIdx.x == 0) args.debug[3000 + 16 * sub + (i)] = (float)(_t - stamp_last); \
     stamp_last = _t;                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                    \
   } while (0)
@@ -268,7 +268,9 @@ struct KernelArgs {
 
 }  // namespace
 
-template <bool RESET>
+// DEBUG instantiations carry the diagnostics dump (tests, phase stamps); the product launches use
+// DEBUG = false so that none of the dump's address arithmetic exists in the shipped kernels.
+template <bool RESET, bool DEBUG>
 __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
   __shared__ TeamLds lds_all[2];
   const int lane = threadIdx.x & (TL - 1);
@@ -293,18 +295,17 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
   const int parent = is_body ? M->parent[lane] : 0;
   const int psrc = parent < 0 ? 0 : parent;
   const int depth = is_body ? M->depth[lane] : -1;
-  int anc[MAXD], child[MAXCH];
-#pragma unroll
-  for (int d = 0; d < MAXD; d++) anc[d] = is_body ? M->anc[d][lane] : -1;
-#pragma unroll
-  for (int k = 0; k < MAXCH; k++) child[k] = is_body ? M->child[k][lane] : -1;
-  const unsigned desc_mask = M->desc_mask[lane];
+  // Everything else about the model is (re)read from the L2-resident struct in the phase that uses
+  // it, through an opaque pointer, so that no constant is live - and spilled - across the solver loop.
+  auto Mo = [&]() { const TrexDeviceModel *Mi = M; asm volatile("" : "+s"(Mi)); return Mi; };
+  int anc[MAXD];
   float axis[3], jpos[3], jrot[9], comb[3], inb[6], sph[4];
+  float mass = 0.f, mscale = 1.f, jdamp = 0.f;
   auto load_body_constants = [&]() {
-    // re-read at the top of every substep from the L2-resident model (opaque pointer: the compiler
-    // must not hoist these loads and then spill 28 registers across the solver loop)
-    const TrexDeviceModel *Mi = M;
-    asm volatile("" : "+s"(Mi));
+    const TrexDeviceModel *Mi = Mo();
+    mscale = args.arr.mass_scale[env * TL + lane];
+    mass = Mi->mass[lane] * mscale;
+    jdamp = Mi->damp[lane];
 #pragma unroll
     for (int c = 0; c < 3; c++) { axis[c] = Mi->axis[c][lane]; jpos[c] = Mi->jpos[c][lane]; comb[c] = Mi->com[c][lane]; }
 #pragma unroll
@@ -314,15 +315,10 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
 #pragma unroll
     for (int c = 0; c < 4; c++) sph[c] = Mi->sphere[c][lane];
   };
-  const float q_lo = M->lower[lane], q_hi = M->upper[lane], jdamp = M->damp[lane];
-  const int hull_v0 = M->hull_start[lane < nb ? lane : nb], hull_v1 = M->hull_start[lane < nb ? lane + 1 : nb];
-  const int obs_slot = is_joint ? M->obs_slot[lane] : -1;
   const int nj = nb - 1;
 
   // ---- per-env state
   float pos[3], quat[4], bv[3], bw[3], q, qd, mtau = 0.f;
-  const float mscale = args.arr.mass_scale[env * TL + lane];
-  const float mass = M->mass[lane] * mscale;
   const float mu = args.arr.friction[env];
   bool motors_on;
   bool do_reset = false;
@@ -347,8 +343,8 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
   }
   float target = 0.f;
   if (!RESET && is_joint) {
-    float a = args.actions[env * nj + obs_slot];
-    target = fminf(fmaxf(a, q_lo), q_hi);  // np.clip, trex_env.py:147
+    const float a = args.actions[env * nj + M->obs_slot[lane]];
+    target = fminf(fmaxf(a, M->lower[lane]), M->upper[lane]);  // np.clip, trex_env.py:147
   }
   const int n_sub = RESET ? (do_reset ? 1 : 0) : (int)M->prm[TP_SUBSTEPS];
   // a team that does not reset still walks through the loop when its wave partner resets
@@ -427,6 +423,12 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
 #if TREX_STAMPS
     unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
 #endif
+    // `ls` = lane, opaque to the optimiser once per substep: lane-derived masks and unit vectors are
+    // then recomputed where used (1 VALU) instead of being hoisted out of the loop and spilled.
+    int ls = lane;
+    asm volatile("" : "+v"(ls));
+    const int bdof_s = ls - nb;
+    const bool is_base_dof_s = bdof_s >= 0 && bdof_s < 6;
     load_body_constants();
     forward_kinematics();
     float vel[6];
@@ -514,6 +516,12 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
 #pragma unroll
     for (int k = 0; k < 6; k++) { U[k] = 0.f; Ud[k] = 0.f; }
     const float tau_j = -jdamp * qd;  // explicit joint damping torque
+    int child[MAXCH];
+    {
+      const TrexDeviceModel *Mi = Mo();
+#pragma unroll
+      for (int k = 0; k < MAXCH; k++) child[k] = is_body ? Mi->child[k][lane] : -1;
+    }
     for (int d = maxdepth; d >= 1; d--) {
       if (depth == d) {
         sym6_mul(IA, S, U);
@@ -647,8 +655,8 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
     float Sd[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) {
-      Sd[k] = is_joint ? S[k] : ((is_base_dof && bdof == k) ? 1.f : 0.f);
-      if (is_base_dof && bdof == k) vg = (k < 3) ? nw[k] : nv[k - 3];
+      Sd[k] = is_joint ? S[k] : ((is_base_dof_s && bdof_s == k) ? 1.f : 0.f);
+      if (is_base_dof_s && bdof_s == k) vg = (k < 3) ? nw[k] : nv[k - 3];
     }
 
     STAMP(4);
@@ -656,6 +664,11 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
     //   Aanc[d-1] = entry at its ancestor of depth d (1 at its own depth), A0 = base block entry,
     //   Z[d-1]    = Aanc[d-1] / D(ancestor), g = I0inv * A0
     float Aanc[MAXD], Z[MAXD], A0[6], g[6];
+    {
+      const TrexDeviceModel *Mi = Mo();
+#pragma unroll
+      for (int d = 0; d < MAXD; d++) anc[d] = is_body ? Mi->anc[d][lane] : -1;
+    }
     {
       float p[6], po[3];   // force p about the point po (starts at this joint's origin, walks up)
 #pragma unroll
@@ -695,7 +708,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
         for (int k = 0; k < 3; k++) p[k] += dxf[k];
       }
 #pragma unroll
-      for (int k = 0; k < 6; k++) A0[k] = is_joint ? -p[k] : ((is_base_dof && bdof == k) ? 1.f : 0.f);
+      for (int k = 0; k < 6; k++) A0[k] = is_joint ? -p[k] : ((is_base_dof_s && bdof_s == k) ? 1.f : 0.f);
       inv21_mul(I0inv, A0, g);
     }
     // response of dof lane to a "row" described by (chain ancestors ca[], z-coefficients zc[], base z0)
@@ -732,8 +745,9 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
         for (int k = 0; k < 6; k++) z0[k] = o[12 + k];
         const float w = response(ca, zc, z0);
         lds.minv[j - 1][lane] = w;
-        if (lane == j) mdiag = w;
+        if (ls == j) mdiag = w;
       }
+      __builtin_amdgcn_sched_barrier(0);   // one column at a time: keeps the staged reads from piling up
     }
 
     STAMP(6);
@@ -741,6 +755,8 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
     const float inv_mdiag = 1.0f / mdiag;
     float lim_dir = 0.f, lim_rhs = 0.f, lim_lam = 0.f;
     if (is_joint) {
+      const TrexDeviceModel *Mi = Mo();
+      const float q_lo = Mi->lower[lane], q_hi = Mi->upper[lane];
       float pen = 0.f;
       if (q - q_lo <= 0.f) { pen = q - q_lo; lim_dir = 1.f; }
       else if (q_hi - q <= 0.f) { pen = q_hi - q; lim_dir = -1.f; }
@@ -765,6 +781,8 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
     int cbody = 0;
     float cx[3] = {0.f, 0.f, 0.f}, cdist = 0.f;
     {
+      const TrexDeviceModel *Mi = Mo();
+      const int hull_v0 = Mi->hull_start[lane < nb ? lane : nb], hull_v1 = Mi->hull_start[lane < nb ? lane + 1 : nb];
       float sc[3];
       matvec3(R, sph, sc);
       const bool near = is_body && hull_v1 > hull_v0 && (pos[2] + r[2] + sc[2] - sph[3] - floor_z < margin);
@@ -976,6 +994,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       o[42] = cx[0]; o[43] = cx[1]; o[44] = cx[2]; o[45] = __int_as_float(cbody);
     }
     __syncthreads();
+    const unsigned desc_mask = Mo()->desc_mask[lane];
     float Jc[MAXC][3], Wc[MAXC][3];
 #pragma unroll
     for (int c = 0; c < MAXC; c++) {
@@ -1006,6 +1025,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
           Wc[c][a] = (c < nc) ? response(ca, zc, z0) : 0.f;
         }
       }
+      __builtin_amdgcn_sched_barrier(0);   // one point at a time
     }
     __syncthreads();
 
@@ -1026,8 +1046,9 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
 #pragma unroll
         for (int k = 0; k < GR; k++) {
           const int r = GR * g + k, c = r / 3, a = r % 3;
-          if (k >= 1) { const float t = tsum(Jc[c][a] * Wc[(r - 1) / 3][(r - 1) % 3]); if (lane == c) c_k1[a] = t; }
-          if (k >= 2) { const float t = tsum(Jc[c][a] * Wc[(r - 2) / 3][(r - 2) % 3]); if (lane == c) c_k2[a] = t; }
+          if (k >= 1) { const float t = tsum(Jc[c][a] * Wc[(r - 1) / 3][(r - 1) % 3]); if (ls == c) c_k1[a] = t; }
+          if (k >= 2) { const float t = tsum(Jc[c][a] * Wc[(r - 2) / 3][(r - 2) % 3]); if (ls == c) c_k2[a] = t; }
+          if (a == 2) __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
@@ -1045,12 +1066,14 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       __builtin_amdgcn_s_waitcnt(0xC07F);
       __builtin_amdgcn_sched_barrier(0);
 #endif
+      int ln = lane;   // opaque once per sweep: `ln == j` is one v_cmp where used, not a spilled mask
+      asm volatile("" : "+v"(ln));
       if (lim_wave) {   // some joint of this wave sits on a stop: all 25 limit rows, branch-free
 #pragma unroll
         for (int j = 1; j <= NJMAX; j++) {
           const float nl = fmaxf(lim_lam + (lim_rhs - lim_dir * dv * inv_mdiag), 0.f);
           float delta = (nl - lim_lam) * lim_dir;   // lim_dir == 0 on lanes without an active row
-          if (lane == j) lim_lam = nl;
+          if (ln == j) lim_lam = nl;
           delta = tbcast(delta, j);
           dv += delta * lds.minv[j - 1][lane];
           if (j % 5 == 0) __builtin_amdgcn_sched_barrier(0);
@@ -1060,7 +1083,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       for (int j = 1; j <= NJMAX; j++) {   // joints beyond nb have mot_hi = 0 and a zero column
         const float nl = __builtin_amdgcn_fmed3f(mot_lam + (mot_rhs - dv * inv_mdiag), -mot_hi, mot_hi);
         float delta = nl - mot_lam;
-        if (lane == j) mot_lam = nl;
+        if (ln == j) mot_lam = nl;
         delta = tbcast(delta, j);
         dv += delta * lds.minv[j - 1][lane];
         if (j % 5 == 0) __builtin_amdgcn_sched_barrier(0);   // prefetch window of 5 columns
@@ -1087,7 +1110,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
             const float lo = (a == 0) ? 0.f : -hi;
             const float nl = __builtin_amdgcn_fmed3f(c_lam[a] + (c_rhs[a] - pa * c_inv[a]), lo, hi);
             float d = nl - c_lam[a];
-            if (lane == c) c_lam[a] = nl;
+            if (ln == c) c_lam[a] = nl;
             d = tbcast(d, c);
             dv += d * Wc[c][a];
             pb += d * c_k1[(a + 1) % 3];                   // K1 of row r+1, exact on that row's owner
@@ -1099,7 +1122,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       }
     }
 #if TREX_STAMPS
-    if (args.debug && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (DEBUG && args.debug && blockIdx.x == 0 && threadIdx.x == 0) {
       args.debug[3000 + 16 * sub + 14] = (float)acc_joint;
       args.debug[3000 + 16 * sub + 15] = (float)lim_wave;
     }
@@ -1108,7 +1131,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
     STAMP(12);
 
 
-    if (args.debug && blockIdx.x == 0 && team == 0) {
+    if (DEBUG && args.debug && blockIdx.x == 0 && team == 0) {
       float *D = args.debug;
       D[lane] = qdd; D[64 + lane] = vg; D[96 + lane] = dv;
       if (lane < 6) D[32 + lane] = a0[lane];
@@ -1192,6 +1215,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
   }
   if (args.obs && is_joint) {
     float *o = args.obs + (size_t)env * 3 * nj;
+    const int obs_slot = M->obs_slot[lane];
     o[obs_slot] = q; o[nj + obs_slot] = qd; o[2 * nj + obs_slot] = mtau;
   }
   if (lane == 0) {
@@ -1287,14 +1311,15 @@ hipError_t trex_launch_step(const TrexDeviceModel *model, TrexBatchArrays arr, i
                             float *obs, float *reward, uint8_t *done, float *penalties, float wd, float we,
                             float wk, float *debug, hipStream_t stream) {
   KernelArgs a{model, arr, n, actions, obs, reward, done, penalties, nullptr, wd, we, wk, debug};
-  hipLaunchKernelGGL(trex_step_kernel<false>, dim3((n + 1) / 2), dim3(64), 0, stream, a);
+  if (debug) hipLaunchKernelGGL((trex_step_kernel<false, true>), dim3((n + 1) / 2), dim3(64), 0, stream, a);
+  else hipLaunchKernelGGL((trex_step_kernel<false, false>), dim3((n + 1) / 2), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
 
 hipError_t trex_launch_reset(const TrexDeviceModel *model, TrexBatchArrays arr, int n, const uint8_t *mask,
                              float *obs, float wd, float we, float wk, float *debug, hipStream_t stream) {
   KernelArgs a{model, arr, n, nullptr, obs, nullptr, nullptr, nullptr, mask, wd, we, wk, debug};
-  hipLaunchKernelGGL(trex_step_kernel<true>, dim3((n + 1) / 2), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL((trex_step_kernel<true, false>), dim3((n + 1) / 2), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
 
