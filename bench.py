@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--domain-rand", action="store_true",
+                    help="BASELINE config 5: per-env body-mass scale U(0.8,1.2) and friction U(0.5,1.25), seed 1")
     ap.add_argument("--param", action="append", default=[],
                     help="engine parameter override name=value (ablations only: the line is then NOT the headline config)")
     args = ap.parse_args()
@@ -100,9 +102,12 @@ def main():
     from trex_gym import sharding
     from trex_gym.vec_env import TrexVecEnv
 
+    if os.environ.get("TREX_BENCH_SHARE_DEVICE"):   # rehearsal of the N>1 path on a one-GPU box
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if world > 1 or under_launcher:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -110,11 +115,17 @@ def main():
     overrides = {k: float(v) for k, v in (p.split("=") for p in args.param)}
     env = TrexVecEnv(n_global, device=dev, rank=rank, world_size=world, params=overrides)
     n_local = env.num_envs
+    if args.domain_rand:
+        g = torch.Generator(device=dev).manual_seed(1)
+        env.set_domain(0.8 + 0.4 * torch.rand(n_local, env.model.num_bodies, device=dev, generator=g),
+                       0.5 + 0.75 * torch.rand(n_local, device=dev, generator=g))
     lo, hi = env.model.lower, env.model.upper
     ids = torch.arange(env.env_lo, env.env_hi, device=dev)
     pool = torch.stack([sharding.synthetic_actions(ids, t, lo, hi, seed=0, device=dev) for t in range(16)])
 
     events = []
+    force_gather = under_launcher and world == 1 and bool(os.environ.get("TREX_BENCH_FORCE_GATHER"))
+    gather_buf = torch.empty_like(env.obs) if force_gather else None
 
     def run(n_steps, t_base, timed=False):
         for t in range(n_steps):
@@ -127,12 +138,14 @@ def main():
                 events.append((e0, e1))
             if world > 1:
                 env.all_gather_obs()
+            elif force_gather:   # one-GPU rehearsal of the collective call itself (RCCL, world of 1)
+                dist.all_gather_into_tensor(gather_buf, env.obs)
             if (t_base + t + 1) % EPISODE_STEPS == 0:
                 env.reset_tensor()
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or under_launcher:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -153,7 +166,7 @@ def main():
     finite = bool(torch.isfinite(env.obs).all().item())
     info = env.batch.launch_info()
     if rank == 0:
-        alg = info["alg_bytes_per_env_step"] * n_local  # bytes per launch
+        alg = (info["alg_bytes_per_env_step"] + (1044 if args.domain_rand else 0)) * n_local  # bytes per launch
         achieved = alg / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -176,6 +189,8 @@ def main():
                                    % (args.envs_per_gpu, world, EPISODE_STEPS,
                                       ", obs all-gather over RCCL each step" if world > 1 else ""),
                        "envs_global": n_global, "parallelism": "env-sharded dp%d" % world,
+                       **({"domain_randomisation": "mass_scale U(0.8,1.2) per body, friction U(0.5,1.25), seed 1"}
+                          if args.domain_rand else {}),
                        **({"ABLATION_param_overrides": overrides} if overrides else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -188,7 +203,7 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or under_launcher:
         dist.destroy_process_group()
 
 

@@ -1,0 +1,53 @@
+"""Training entry point with the reference's flags (trex_train.py:24-29,113-136), driving the GPU
+vec env with the on-device PPO of trex_gym.ppo instead of baselines.ppo2 + TF1.
+
+    python -m trex_gym.trex_train --num_timesteps 5000000 --num_envs 4096
+
+Reward weights are the training ones of the reference (distance 2e2, energy 1e-6, drift 1.0,
+trex_train.py:66). --play / --debug_render need pybullet's renderer and are out of scope.
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+from .ppo import PPO
+from .vec_env import TrexVecEnv
+
+_URDF_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "assets", "trex_collide.urdf")
+
+
+def build_environment(num_envs, device="cuda:0", max_episode_steps=1000):
+    return TrexVecEnv(num_envs, urdf_path=_URDF_PATH, device=device, distance_weight=2e2, energy_weight=1e-6,
+                      drift_weight=1.0, max_episode_steps=max_episode_steps)
+
+
+def train(env, num_timesteps, seed, nsteps=32, noptepochs=4, save_path=None, log=print):
+    agent = PPO(env, nsteps=nsteps, nminibatches=32, noptepochs=noptepochs, lam=0.95, gamma=0.99, lr=3e-4,
+                cliprange=0.2, ent_coef=0.0, seed=seed)
+    log("Number of actions: %d; number of joints: %d; model mass: %.2f; nsteps %d x %d envs; noptepochs %d"
+        % (env.action_space.shape[0], env.model.num_joints, env.model.total_mass(False), nsteps, env.num_envs, noptepochs))
+    hist = agent.learn(num_timesteps, log=log)
+    if save_path:
+        torch.save({"policy": agent.policy.state_dict(), "obs_mean": agent.obs_rms.mean, "obs_var": agent.obs_rms.var},
+                   save_path)
+    return agent, hist
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--train", action="store_true", default=True)
+    ap.add_argument("--num_timesteps", type=int, default=int(5e6))   # trex_train.py:27
+    ap.add_argument("--random_seed", type=int, default=0)            # trex_train.py:29
+    ap.add_argument("--num_envs", type=int, default=4096)
+    ap.add_argument("--nsteps", type=int, default=32)
+    ap.add_argument("--noptepochs", type=int, default=4)
+    ap.add_argument("--save", type=str, default=None)
+    args = ap.parse_args(argv)
+    env = build_environment(args.num_envs)
+    train(env, args.num_timesteps, args.random_seed, args.nsteps, args.noptepochs, args.save)
+
+
+if __name__ == "__main__":
+    sys.exit(main())
