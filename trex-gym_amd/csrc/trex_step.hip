@@ -976,6 +976,16 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
     }
     STAMP(9);
     const int ncw = max(nc, __shfl_xor(nc, 32));  // both teams walk the same number of points
+    // The launch lasts as long as its heaviest wave (profiles/r01_v7_sq_counters.md: the mean wave
+    // lives 32 % of it). Let a wave with many contact rows win the issue arbitration against its
+    // lighter SIMD partner: priority = number of 4-point groups it has to sweep.
+    {
+      const int groups = __builtin_amdgcn_readfirstlane((ncw + 3) >> 2);
+      if (groups >= 4) __builtin_amdgcn_s_setprio(3);
+      else if (groups == 3) __builtin_amdgcn_s_setprio(2);
+      else if (groups == 2) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
     // Per point c (static index -> registers): this dof lane's Jacobian entries Jc[c][a] = velocity of
     // the point per unit dof rate along normal z / friction x / friction y, and the response Wc[c][a].
     // Lane c publishes its point (chain, z-coefficients, position, body: 46 floats) in the stage.
