@@ -324,12 +324,14 @@ def compile_model(urdf_path, collisions_dir=None, start_configuration=None):
     m["total_mass"] = float(sum(l["mass"] for l in links))
     m["total_mass_excluding_base"] = float(sum(l["mass"] for l in links if l["name"] != root))
 
-    cfg = dict(START_CONFIGURATION)
-    if start_configuration is not None:
-        cfg = {rename_v0_name(k): v for k, v in start_configuration.items()}
     q0 = np.zeros(nb)
-    for k, v in cfg.items():
-        q0[m["joint_names"].index(k)] = v  # KeyError-equivalent: ValueError on unknown joint
+    if start_configuration is None:   # the env's default pose, where those joints exist (generic URDFs: zeros)
+        for k, v in START_CONFIGURATION.items():
+            if k in m["joint_names"]:
+                q0[m["joint_names"].index(k)] = v
+    else:
+        for k, v in start_configuration.items():
+            q0[m["joint_names"].index(rename_v0_name(k))] = v  # unknown joint raises, like KeyError at trex_robot.py:307
     m["q_start"] = q0
     m["base_start_pos"] = np.array([0.0, 0.0, 3.0])  # trex_env.py:105
     m["base_start_quat"] = np.array([0.0, 0.0, 0.0, 1.0])  # rpy = 0, trex_env.py:106

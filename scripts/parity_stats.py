@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""One-step parity error statistics of the HIP kernel vs the f64 oracle over many states
+(golden rollouts + a landing with noisy actions). Prints the distribution that the tolerances of
+tests/test_gpu_parity.py are set from. Run on the GPU box."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "trex-gym_amd"))
+from oracle import oracle as O, trex_model as tm  # noqa: E402
+from trex_gym.vec_env import TrexVecEnv  # noqa: E402
+
+
+def main():
+    om = tm.compile_model(O.default_asset_urdf())
+    orc = O.Oracle(om)
+    order = om["obs_order"]
+    lo, hi, q0 = om["q_lower"][order], om["q_upper"][order], om["q_start"][order]
+    rng = np.random.default_rng(11)
+    states, acts = [], []
+    for mode in ("hold", "random", "zero"):
+        s = orc.new_state()
+        orc.reset(s)
+        for t in range(250):
+            a = {"hold": np.clip(q0 + 0.15 * rng.normal(size=25), lo, hi), "random": rng.uniform(lo, hi),
+                 "zero": np.zeros(25)}[mode]
+            orc.step(s, a)
+            if t % 3 == 0:
+                states.append(orc.get_state(s).astype(np.float32))
+                acts.append(rng.uniform(lo, hi).astype(np.float32) if mode != "hold" else
+                            np.clip(q0 + 0.15 * rng.normal(size=25), lo, hi).astype(np.float32))
+    states, acts = np.array(states), np.array(acts)
+    n = len(states)
+    v = TrexVecEnv(n, device="cuda:0")
+    v.reset()
+    v.set_state(torch.tensor(states))
+    obs, rew, _, _ = v.step(acts)
+    eq, eqd, etau, erew, ncs = [], [], [], [], []
+    for k in range(n):
+        s2 = orc.new_state()
+        orc.set_state(s2, states[k].astype(np.float64))
+        o, r, _ = orc.step(s2, acts[k].astype(np.float64))
+        eq.append(np.abs(obs[k, :25] - o[:25]).max())
+        eqd.append(np.abs(obs[k, 25:50] - o[25:50]).max() / max(1.0, np.abs(o[25:50]).max()))
+        etau.append(np.abs(obs[k, 50:] - o[50:]).max() / (np.abs(o[50:]).max() + 1.0))
+        erew.append(abs(rew[k] - r) / (abs(r) + 1e-3))
+        ncs.append(len(orc.contacts(s2)[0]))
+    ncs = np.array(ncs)
+    for name, e in (("|dq| [rad]", eq), ("|dqd| / max(1,|qd|)", eqd), ("|dtau| / max|tau|", etau), ("|dr| / |r|", erew)):
+        e = np.array(e)
+        print("%-22s median %.2e  p90 %.2e  p99 %.2e  max %.2e   (in contact: max %.2e, airborne: max %.2e)"
+              % (name, np.median(e), np.percentile(e, 90), np.percentile(e, 99), e.max(),
+                 e[ncs > 0].max() if (ncs > 0).any() else 0, e[ncs == 0].max() if (ncs == 0).any() else 0))
+    print("states %d, of which in contact %d" % (n, (ncs > 0).sum()))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,102 @@
+"""Physics invariants checked ON THE GPU PATH itself (not only on the oracle), and a second, tiny
+model through the same kernel: the HIP code is not specialised to the T-rex tree."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import ASSET_URDF
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+PENDULUM = """<robot name='p'>
+  <link name='base'><inertial><origin xyz='0 0 0' rpy='0 0 0'/><mass value='1000'/><inertia ixx='500' iyy='500' izz='500'/></inertial></link>
+  <link name='arm'><inertial><origin xyz='0 0 -0.5' rpy='0 0 0'/><mass value='1'/><inertia ixx='0.02' iyy='0.02' izz='0.001'/></inertial></link>
+  <link name='fore'><inertial><origin xyz='0 0 -0.3' rpy='0 0 0'/><mass value='0.5'/><inertia ixx='0.01' iyy='0.01' izz='0.001'/></inertial></link>
+  <joint name='shoulder' type='revolute'><parent link='base'/><child link='arm'/><origin xyz='0 0 0' rpy='0 0 0'/><axis xyz='0 1 0'/><limit lower='-3' upper='3'/></joint>
+  <joint name='elbow' type='revolute'><parent link='arm'/><child link='fore'/><origin xyz='0 0 -1' rpy='0 0 0'/><axis xyz='0 1 0'/><limit lower='-3' upper='3'/></joint>
+</robot>"""
+
+
+def test_free_fall_and_momentum_on_gpu(model):
+    """Motors off, damping off, high above the floor: the COM accelerates at -g and horizontal momentum
+    is conserved - evaluated from the GPU state alone."""
+    from trex_gym import _capi
+    m = _capi.Model(ASSET_URDF)
+    m.set_param("link_damping", 0.0)
+    m.set_param("motor_max_force", 0.0)
+    m.set_param("substeps", 50)
+    b = _capi.Batch(m, 4)
+    rng = np.random.default_rng(0)
+    st = np.zeros((4, 63), np.float32)
+    st[:, 2] = 60.0
+    q = rng.normal(size=(4, 4)); st[:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    st[:, 7:13] = 0.3 * rng.normal(size=(4, 6))
+    lo, hi = model["q_lower"][model["obs_order"]], model["q_upper"][model["obs_order"]]
+    st[:, 13:38] = rng.uniform(0.5 * lo, 0.5 * hi, (4, 25))
+    st[:, 38:] = 0.3 * rng.normal(size=(4, 25))
+    # joint damping is a URDF property (1.0 N m s): its torques are internal, momentum is unaffected
+    dev_st = torch.tensor(st, device=DEV)
+    b.set_state(dev_st)
+    b.set_motors_enabled(True)
+
+    def com_and_momentum(state_row):
+        # FK on the host from the GPU state (numpy oracle model only for masses/geometry)
+        from oracle import oracle as O
+        orc = O.Oracle(model)
+        s = orc.new_state()
+        orc.set_state(s, state_row.astype(np.float64))
+        e = orc.energy(s)
+        pos, rot = orc.body_poses(s)
+        mt = model["mass"].sum()
+        com = sum(model["mass"][i] * (pos[i] + rot[i] @ model["com"][i]) for i in range(model["nb"])) / mt
+        return com, e["momentum"][3:6], mt
+    c0 = [com_and_momentum(r) for r in st]
+    obs = torch.zeros(4, 75, device=DEV); rew = torch.zeros(4, device=DEV); done = torch.zeros(4, dtype=torch.uint8, device=DEV)
+    b.step(torch.zeros(4, 25, device=DEV), obs, rew, done)     # 50 substeps = 0.1 s
+    out = torch.zeros(4, 63, device=DEV)
+    b.get_state(out)
+    st1 = out.cpu().numpy()
+    t = 50 * 0.002
+    for k in range(4):
+        com1, mom1, mt = com_and_momentum(st1[k])
+        com0, mom0, _ = c0[k]
+        v0 = mom0 / mt
+        want = com0 + v0 * t + np.array([0, 0, -0.5 * 9.81 * t * (t + 0.002)])   # semi-implicit Euler sum
+        np.testing.assert_allclose(com1, want, atol=2e-4)
+        np.testing.assert_allclose(mom1 - mom0, [0, 0, -mt * 9.81 * t], atol=2e-4 * mt)
+
+
+def test_double_pendulum_model_through_the_same_kernel(tmp_path):
+    """A 3-body URDF (heavy base + two-link pendulum), no hulls: kernel vs oracle on a different tree."""
+    from oracle import oracle as O, trex_model as tm
+    from trex_gym import _capi
+    u = tmp_path / "pend.urdf"
+    u.write_text(PENDULUM)
+    om = tm.compile_model(str(u))
+    assert om["nb"] == 3
+    orc = O.Oracle(om, params=dict(link_damping=0.0))
+    m = _capi.Model(str(u))
+    m.set_param("link_damping", 0.0)
+    m.set_start_pose([0, 0, 5.0], [0, 0, 0])
+    m.set_start_angle("shoulder", 0.7)
+    om["q_start"][om["joint_names"].index("shoulder")] = 0.7
+    om["base_start_pos"] = np.array([0, 0, 5.0])
+    orc = O.Oracle(om, params=dict(link_damping=0.0))
+    b = _capi.Batch(m, 3)
+    obs = torch.zeros(3, 6, device=DEV); rew = torch.zeros(3, device=DEV); done = torch.zeros(3, dtype=torch.uint8, device=DEV)
+    b.reset(obs)
+    s = orc.new_state()
+    o0 = orc.reset(s)
+    np.testing.assert_allclose(obs.cpu().numpy()[0], o0, atol=1e-6)
+    a = torch.tensor([[0.2, -0.4]] * 3, device=DEV)
+    for t in range(40):
+        b.step(a, obs, rew, done)
+        o, r, _ = orc.step(s, np.array([0.2, -0.4]))
+    g = obs.cpu().numpy()
+    assert (g == g[0]).all()
+    np.testing.assert_allclose(g[0, :2], o[:2], atol=2e-5)
+    np.testing.assert_allclose(g[0, 2:4], o[2:4], atol=2e-4)
+    np.testing.assert_allclose(g[0, 4:], o[4:], atol=2e-3 * (np.abs(o[4:]).max() + 1))
+    # the position motor pulls the joints toward their targets
+    assert abs(g[0, 0] - 0.2) < abs(0.7 - 0.2) and abs(g[0, 1] + 0.4) < 0.4

@@ -3,9 +3,11 @@
 committed golden rollouts, and - at BASELINE's full 4096 envs - through size-independent properties.
 
 Stated tolerances (f32 kernel vs f64 oracle; PGS amplifies rounding in contact):
-  one env-step from an identical state: |dq| <= 2e-4 rad, |dqd| <= 1e-2 * max(1, |qd|_inf),
-  motor torque <= 2e-2 * max|tau| (+1 N m), reward <= 2e-3 relative (+1e-3)
+  one env-step from an identical state: |dq| <= 1e-4 rad, |dqd| <= 5e-3 * max(1, |qd|_inf),
+  motor torque <= 5e-3 * max|tau| (+1 N m), reward <= 2e-3 relative (+1e-3)
   contact-free trajectories (8..25 steps): |dq| <= 1e-4, |dqd| <= 5e-4 * max(1, |qd|_inf)
+Measured over 252 states, 152 of them in contact (scripts/parity_stats.py): max |dq| 3.7e-5,
+|dqd| 7.7e-4, torque 9.0e-4, reward 3.8e-4 (medians 1e-7 .. 3e-6); airborne states 3e-7 .. 1e-5.
 """
 import os
 
@@ -34,10 +36,10 @@ def make_vec(n, **kw):
 def assert_step_close(g_obs, o_obs, g_rew=None, o_rew=None, what=""):
     J = 25
     assert np.isfinite(g_obs).all(), what
-    np.testing.assert_allclose(g_obs[:J], o_obs[:J], atol=2e-4, rtol=0, err_msg=what + " q")
-    np.testing.assert_allclose(g_obs[J:2 * J], o_obs[J:2 * J], atol=1e-2 * max(1.0, np.abs(o_obs[J:2 * J]).max()),
+    np.testing.assert_allclose(g_obs[:J], o_obs[:J], atol=1e-4, rtol=0, err_msg=what + " q")
+    np.testing.assert_allclose(g_obs[J:2 * J], o_obs[J:2 * J], atol=5e-3 * max(1.0, np.abs(o_obs[J:2 * J]).max()),
                                rtol=0, err_msg=what + " qd")
-    np.testing.assert_allclose(g_obs[2 * J:], o_obs[2 * J:], atol=2e-2 * np.abs(o_obs[2 * J:]).max() + 1.0, rtol=0,
+    np.testing.assert_allclose(g_obs[2 * J:], o_obs[2 * J:], atol=5e-3 * np.abs(o_obs[2 * J:]).max() + 1.0, rtol=0,
                                err_msg=what + " tau")
     if g_rew is not None:
         assert abs(g_rew - o_rew) <= 2e-3 * abs(o_rew) + 1e-3, (what, g_rew, o_rew)
