@@ -38,6 +38,12 @@
 #ifndef TREX_STAMPS
 #define TREX_STAMPS 0
 #endif
+// Contact-row variant. 0: the owner lane finishes a row from its registers and the impulse change is
+// broadcast with two v_readlane. 1: every lane finishes the row redundantly - row constants arrive as a
+// team-wide LDS broadcast prefetched two rows ahead, impulses are replicated in registers (48 VGPRs).
+#ifndef TREX_CONTACT_REPLICATED
+#define TREX_CONTACT_REPLICATED 1
+#endif
 // Diagnostic build only (make stamps): s_memtime at phase boundaries of workgroup 0, written to the
 // debug buffer at [3000 + 16*substep + phase] as cycle deltas. Never compiled into the product library.
 #if TREX_STAMPS
@@ -247,6 +253,7 @@ __device__ __forceinline__ void inv21_mul(const float *inv21, const float *v, fl
 constexpr int NJMAX = TL - 7;   // 25 hinge joints at most (26 bodies + 6 base dofs = 32 lanes)
 struct TeamLds {
   float minv[NJMAX][TL];    // [j-1][dof lane]: column j of M^-1 (motor / limit row responses)       3200 B
+  float4 crow[MAXC * 3];    // contact rows {rhs, 1/diag, K1, K2} (TREX_CONTACT_REPLICATED)          768 B
   float aba[TL][28];        // tip-to-base staging: Ia (21) + pa (6) per body; afterwards reused as the
                             // broadcast stage for the M^-1 columns and the contact blocks        3584 B
 };
@@ -1058,11 +1065,20 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
           const int r = GR * g + k, c = r / 3, a = r % 3;
           if (k >= 1) { const float t = tsum(Jc[c][a] * Wc[(r - 1) / 3][(r - 1) % 3]); if (ls == c) c_k1[a] = t; }
           if (k >= 2) { const float t = tsum(Jc[c][a] * Wc[(r - 2) / 3][(r - 2) % 3]); if (ls == c) c_k2[a] = t; }
+#if TREX_CONTACT_REPLICATED
+          if (ls == c) lds.crow[r] = (c < nc) ? make_float4(c_rhs[a], c_inv[a], c_k1[a], c_k2[a]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
           if (a == 2) __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
     c_lam[0] = c_lam[1] = c_lam[2] = 0.f;
+#if TREX_CONTACT_REPLICATED
+    __syncthreads();
+    float lam[MAXC][3];
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) { lam[c][0] = 0.f; lam[c][1] = 0.f; lam[c][2] = 0.f; }
+#endif
     STAMP(11);
     float dv = 0.f;
     const unsigned lim_wave = lim_mask | (unsigned)__shfl_xor((int)lim_mask, 32);
@@ -1110,6 +1126,29 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
         if (GP * g < ncw) {
           const int r0 = GR * g;
           float pa = tsum(Jc[r0 / 3][0] * dv), pb = tsum(Jc[r0 / 3][1] * dv);
+#if TREX_CONTACT_REPLICATED
+          float4 qa = lds.crow[r0], qb = lds.crow[r0 + 1];
+#pragma unroll
+          for (int k = 0; k < GR; k++) {
+            const int r = r0 + k, c = r / 3, a = r % 3;
+            float pc = 0.f;
+            float4 qc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k + 2 < GR) {   // rows r, r+1 still missing from this reduction
+              qc = lds.crow[r + 2];
+              pc = tsum(Jc[(r + 2) / 3][(r + 2) % 3] * dv);
+            }
+            const float hi = (a == 0) ? 1.0e30f : mu * lam[c][0];
+            const float lo = (a == 0) ? 0.f : -hi;
+            const float nl = __builtin_amdgcn_fmed3f(lam[c][a] + (qa.x - pa * qa.y), lo, hi);
+            const float d = nl - lam[c][a];
+            lam[c][a] = nl;
+            dv += d * Wc[c][a];
+            pb += d * qb.z;                    // K1 of row r+1
+            if (k + 2 < GR) pc += d * qc.w;    // K2 of row r+2
+            pa = pb; pb = pc; qa = qb; qb = qc;
+            if (a == 2) __builtin_amdgcn_sched_barrier(0);  // bound live ranges: one point per window
+          }
+#else
 #pragma unroll
           for (int k = 0; k < GR; k++) {
             const int r = r0 + k, c = r / 3, a = r % 3;
@@ -1128,9 +1167,15 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
             pa = pb; pb = pc;
             if (a == 2) __builtin_amdgcn_sched_barrier(0);  // bound live ranges: one point per window
           }
+#endif
         }
       }
     }
+#if TREX_CONTACT_REPLICATED
+#pragma unroll
+    for (int c = 0; c < MAXC; c++)
+      if (ls == c) { c_lam[0] = lam[c][0]; c_lam[1] = lam[c][1]; c_lam[2] = lam[c][2]; }
+#endif
 #if TREX_STAMPS
     if (DEBUG && args.debug && blockIdx.x == 0 && threadIdx.x == 0) {
       args.debug[3000 + 16 * sub + 14] = (float)acc_joint;
