@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--domain-rand", action="store_true",
                     help="BASELINE config 5: per-env body-mass scale U(0.8,1.2) and friction U(0.5,1.25), seed 1")
+    ap.add_argument("--action-scale", type=float, default=1.0,
+                    help="ablation: sample actions from the joint range widened by this factor (>1 pins joints on their stops)")
     ap.add_argument("--param", action="append", default=[],
                     help="engine parameter override name=value (ablations only: the line is then NOT the headline config)")
     args = ap.parse_args()
@@ -121,7 +123,10 @@ def main():
                        0.5 + 0.75 * torch.rand(n_local, device=dev, generator=g))
     lo, hi = env.model.lower, env.model.upper
     ids = torch.arange(env.env_lo, env.env_hi, device=dev)
-    pool = torch.stack([sharding.synthetic_actions(ids, t, lo, hi, seed=0, device=dev) for t in range(16)])
+    mid, half = 0.5 * (lo + hi), 0.5 * (hi - lo) * args.action_scale
+    pool = torch.stack([sharding.synthetic_actions(ids, t, mid - half, mid + half, seed=0, device=dev) for t in range(16)])
+    if args.action_scale != 1.0:
+        overrides = dict(overrides, action_scale=args.action_scale)
 
     events = []
     force_gather = under_launcher and world == 1 and bool(os.environ.get("TREX_BENCH_FORCE_GATHER"))

@@ -1094,16 +1094,15 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
 #endif
       int ln = lane;   // opaque once per sweep: `ln == j` is one v_cmp where used, not a spilled mask
       asm volatile("" : "+v"(ln));
-      if (lim_wave) {   // some joint of this wave sits on a stop: all 25 limit rows, branch-free
-#pragma unroll
-        for (int j = 1; j <= NJMAX; j++) {
-          const float nl = fmaxf(lim_lam + (lim_rhs - lim_dir * dv * inv_mdiag), 0.f);
-          float delta = (nl - lim_lam) * lim_dir;   // lim_dir == 0 on lanes without an active row
-          if (ln == j) lim_lam = nl;
-          delta = tbcast(delta, j);
-          dv += delta * lds.minv[j - 1][lane];
-          if (j % 5 == 0) __builtin_amdgcn_sched_barrier(0);
-        }
+      // limit rows: only the joints that sit on a stop in either env of the wave (ascending joint
+      // order, as the oracle); j is wave-uniform, so the broadcast is still two v_readlane
+      for (unsigned m = lim_wave; m != 0u; m &= m - 1u) {
+        const int j = __builtin_amdgcn_readfirstlane(__ffs(m) - 1);
+        const float nl = fmaxf(lim_lam + (lim_rhs - lim_dir * dv * inv_mdiag), 0.f);
+        float delta = (nl - lim_lam) * lim_dir;   // lim_dir == 0 on lanes without an active row
+        if (ln == j) lim_lam = nl;
+        delta = tbcast(delta, j);
+        dv += delta * lds.minv[j - 1][lane];
       }
 #pragma unroll
       for (int j = 1; j <= NJMAX; j++) {   // joints beyond nb have mot_hi = 0 and a zero column
