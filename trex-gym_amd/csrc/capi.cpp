@@ -110,6 +110,9 @@ void fill_device_model(const trex::HostModel &h, TrexDeviceModel &d) {
     d.q_start[b] = (float)h.q_start[b];
     d.sphere[0][b] = (float)sc.x; d.sphere[1][b] = (float)sc.y; d.sphere[2][b] = (float)sc.z;
     d.sphere[3][b] = (float)h.sphere_radius[b];
+    // round the half extents up one ulp-ish: the bound must stay conservative in f32
+    d.box_half[0][b] = (float)(h.box_half[b].x * (1 + 1e-6) + 1e-7); d.box_half[1][b] = (float)(h.box_half[b].y * (1 + 1e-6) + 1e-7);
+    d.box_half[2][b] = (float)(h.box_half[b].z * (1 + 1e-6) + 1e-7);
     d.hull_start[b] = h.hull_start[b];
   }
   for (int b = h.nb; b <= TREX_TL; b++) d.hull_start[b] = h.hull_start[h.nb];

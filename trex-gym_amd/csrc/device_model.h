@@ -29,6 +29,7 @@ struct TrexDeviceModel {
   float axis[3][TREX_TL], jpos[3][TREX_TL], jrot[9][TREX_TL], com[3][TREX_TL], inertia[6][TREX_TL];
   float mass[TREX_TL], lower[TREX_TL], upper[TREX_TL], damp[TREX_TL], q_start[TREX_TL];
   float sphere[4][TREX_TL];           /* bounding sphere of the body's hull vertices: cx cy cz r */
+  float box_half[3][TREX_TL];         /* half extents of their body-frame AABB (same centre): the broad-phase bound */
 };
 
 /* Per-env state in HBM. One row per env, padded so that a 32-lane team reads whole 128-B segments:

@@ -353,7 +353,7 @@ HostModel load_model(const std::string &urdf_path, const char *collisions_dir, i
     m.parent.resize(nb); m.depth.assign(nb, 0);
     m.joint_axis.resize(nb); m.joint_pos.resize(nb); m.joint_rot.resize(nb); m.com.resize(nb);
     m.q_lower.assign(nb, 0); m.q_upper.assign(nb, 0); m.joint_damping.assign(nb, 0); m.mass.assign(nb, 0);
-    m.inertia.resize(nb); m.sphere_center.resize(nb); m.sphere_radius.assign(nb, 0); m.q_start.assign(nb, 0);
+    m.inertia.resize(nb); m.sphere_center.resize(nb); m.box_half.resize(nb); m.sphere_radius.assign(nb, 0); m.q_start.assign(nb, 0);
     m.hull_start.push_back(0);
     std::vector<int> n_children(nb, 0);
     for (int i = 0; i < nb; i++) {
@@ -415,6 +415,7 @@ HostModel load_model(const std::string &urdf_path, const char *collisions_dir, i
         double r2 = 0;
         for (size_t v = before; v < m.hull_xyz.size(); v++) r2 = std::max(r2, dot(m.hull_xyz[v] - c, m.hull_xyz[v] - c));
         m.sphere_center[i] = c; m.sphere_radius[i] = std::sqrt(r2);
+        m.box_half[i] = 0.5 * (hi - lo);
       }
       m.hull_start.push_back((int)m.hull_xyz.size());
     }

@@ -41,7 +41,7 @@ struct HostModel {
   int num_urdf_joints = 0;
   std::vector<std::string> body_names, joint_names;  // per body (joint_names[0] empty)
   std::vector<int> parent, depth;
-  std::vector<Vec3> joint_axis, joint_pos, com, sphere_center;
+  std::vector<Vec3> joint_axis, joint_pos, com, sphere_center, box_half;  // box: AABB of the hull in the body frame (centre = sphere_center)
   std::vector<Mat3> joint_rot;
   std::vector<double> q_lower, q_upper, joint_damping, mass, sphere_radius, q_start;
   std::vector<std::array<double, 6>> inertia;  // xx xy xz yy yz zz about COM, body axes

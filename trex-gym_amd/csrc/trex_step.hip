@@ -38,12 +38,6 @@
 #ifndef TREX_STAMPS
 #define TREX_STAMPS 0
 #endif
-// Contact-row variant. 0: the owner lane finishes a row from its registers and the impulse change is
-// broadcast with two v_readlane. 1: every lane finishes the row redundantly - row constants arrive as a
-// team-wide LDS broadcast prefetched two rows ahead, impulses are replicated in registers (48 VGPRs).
-#ifndef TREX_CONTACT_REPLICATED
-#define TREX_CONTACT_REPLICATED 1
-#endif
 // Diagnostic build only (make stamps): s_memtime at phase boundaries of workgroup 0, written to the
 // debug buffer at [3000 + 16*substep + phase] as cycle deltas. Never compiled into the product library.
 #if TREX_STAMPS
@@ -253,7 +247,7 @@ __device__ __forceinline__ void inv21_mul(const float *inv21, const float *v, fl
 constexpr int NJMAX = TL - 7;   // 25 hinge joints at most (26 bodies + 6 base dofs = 32 lanes)
 struct TeamLds {
   float minv[NJMAX][TL];    // [j-1][dof lane]: column j of M^-1 (motor / limit row responses)       3200 B
-  float4 crow[MAXC * 3];    // contact rows {rhs, 1/diag, K1, K2} (TREX_CONTACT_REPLICATED)          768 B
+  float4 crow[MAXC * 3];    // contact rows {rhs, 1/diag, K1, K2}, read back as a team-wide broadcast  768 B
   float aba[TL][28];        // tip-to-base staging: Ia (21) + pa (6) per body; afterwards reused as the
                             // broadcast stage for the M^-1 columns and the contact blocks        3584 B
 };
@@ -306,7 +300,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
   // it, through an opaque pointer, so that no constant is live - and spilled - across the solver loop.
   auto Mo = [&]() { const TrexDeviceModel *Mi = M; asm volatile("" : "+s"(Mi)); return Mi; };
   int anc[MAXD];
-  float axis[3], jpos[3], jrot[9], comb[3], inb[6], sph[4];
+  float axis[3], jpos[3], jrot[9], comb[3], inb[6], sph[3], boxh[3];
   float mass = 0.f, mscale = 1.f, jdamp = 0.f;
   auto load_body_constants = [&]() {
     const TrexDeviceModel *Mi = Mo();
@@ -320,7 +314,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
 #pragma unroll
     for (int c = 0; c < 6; c++) inb[c] = Mi->inertia[c][lane];
 #pragma unroll
-    for (int c = 0; c < 4; c++) sph[c] = Mi->sphere[c][lane];
+    for (int c = 0; c < 3; c++) { sph[c] = Mi->sphere[c][lane]; boxh[c] = Mi->box_half[c][lane]; }
   };
   const int nj = nb - 1;
 
@@ -792,7 +786,10 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       const int hull_v0 = Mi->hull_start[lane < nb ? lane : nb], hull_v1 = Mi->hull_start[lane < nb ? lane + 1 : nb];
       float sc[3];
       matvec3(R, sph, sc);
-      const bool near = is_body && hull_v1 > hull_v0 && (pos[2] + r[2] + sc[2] - sph[3] - floor_z < margin);
+      // broad phase: lowest point of the hull's oriented bounding box (conservative, much tighter than
+      // a sphere for the long bones): z_centre - sum_k |R_zk| half_k
+      const float reach = fabsf(R[6]) * boxh[0] + fabsf(R[7]) * boxh[1] + fabsf(R[8]) * boxh[2];
+      const bool near = is_body && hull_v1 > hull_v0 && (pos[2] + r[2] + sc[2] - reach - floor_z < margin);
       unsigned near_mask = tballot(near);
       unsigned active_mask = 0u;
       float a_x[3] = {0.f, 0.f, 0.f}, a_d = 0.f;   // lane b: deepest candidate of body b
@@ -1051,10 +1048,11 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
     // early from the dv of that moment and completed with the scalar couplings K1_r = J_r.W_(r-1),
     // K2_r = J_r.W_(r-2) once those rows' impulse changes are known - identical arithmetic up to
     // rounding (J.(dv + d W) = J.dv + d (J.W)), but the dependent chain per row shrinks from
-    // reduce+solve to correct+solve. Row constants {rhs, 1/diag, K1, K2, lambda} live in the
-    // registers of the point's OWNER lane (lane c for point c); the all-reduced J.dv is present on
-    // every lane, the owner finishes the row and two v_readlane broadcast the impulse change.
-    // No LDS and no exec branch inside a row. Rows run in groups of 4 points (one basic block each).
+    // reduce+solve to correct+solve. The all-reduced J.dv is present on every lane, so every lane
+    // finishes the row redundantly: the row constants {rhs, 1/diag, K1, K2} arrive as a team-wide LDS
+    // broadcast prefetched two rows ahead, the impulses are replicated in registers (48 VGPRs), and
+    // nothing has to be broadcast back. No exec branch inside a row; rows run in groups of 4 points
+    // (one basic block each) with the scheduler's window bounded to one point.
     constexpr int GP = 4, GR = 3 * GP;
     float c_k1[3] = {0.f, 0.f, 0.f}, c_k2[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -1065,20 +1063,16 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
           const int r = GR * g + k, c = r / 3, a = r % 3;
           if (k >= 1) { const float t = tsum(Jc[c][a] * Wc[(r - 1) / 3][(r - 1) % 3]); if (ls == c) c_k1[a] = t; }
           if (k >= 2) { const float t = tsum(Jc[c][a] * Wc[(r - 2) / 3][(r - 2) % 3]); if (ls == c) c_k2[a] = t; }
-#if TREX_CONTACT_REPLICATED
           if (ls == c) lds.crow[r] = (c < nc) ? make_float4(c_rhs[a], c_inv[a], c_k1[a], c_k2[a]) : make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
           if (a == 2) __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
     c_lam[0] = c_lam[1] = c_lam[2] = 0.f;
-#if TREX_CONTACT_REPLICATED
     __syncthreads();
-    float lam[MAXC][3];
+    float lam[MAXC][3];   // contact impulses, replicated on every lane of the team
 #pragma unroll
     for (int c = 0; c < MAXC; c++) { lam[c][0] = 0.f; lam[c][1] = 0.f; lam[c][2] = 0.f; }
-#endif
     STAMP(11);
     float dv = 0.f;
     const unsigned lim_wave = lim_mask | (unsigned)__shfl_xor((int)lim_mask, 32);
@@ -1125,7 +1119,6 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
         if (GP * g < ncw) {
           const int r0 = GR * g;
           float pa = tsum(Jc[r0 / 3][0] * dv), pb = tsum(Jc[r0 / 3][1] * dv);
-#if TREX_CONTACT_REPLICATED
           float4 qa = lds.crow[r0], qb = lds.crow[r0 + 1];
 #pragma unroll
           for (int k = 0; k < GR; k++) {
@@ -1147,34 +1140,12 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
             pa = pb; pb = pc; qa = qb; qb = qc;
             if (a == 2) __builtin_amdgcn_sched_barrier(0);  // bound live ranges: one point per window
           }
-#else
-#pragma unroll
-          for (int k = 0; k < GR; k++) {
-            const int r = r0 + k, c = r / 3, a = r % 3;
-            float pc = 0.f;
-            if (k + 2 < GR) pc = tsum(Jc[(r + 2) / 3][(r + 2) % 3] * dv);   // rows r, r+1 still missing
-            // owner lane c: finish row r (other lanes compute on their own, unused, values)
-            const float hi = (a == 0) ? 1.0e30f : mu * c_lam[0];
-            const float lo = (a == 0) ? 0.f : -hi;
-            const float nl = __builtin_amdgcn_fmed3f(c_lam[a] + (c_rhs[a] - pa * c_inv[a]), lo, hi);
-            float d = nl - c_lam[a];
-            if (ln == c) c_lam[a] = nl;
-            d = tbcast(d, c);
-            dv += d * Wc[c][a];
-            pb += d * c_k1[(a + 1) % 3];                   // K1 of row r+1, exact on that row's owner
-            if (k + 2 < GR) pc += d * c_k2[(a + 2) % 3];   // K2 of row r+2, exact on that row's owner
-            pa = pb; pb = pc;
-            if (a == 2) __builtin_amdgcn_sched_barrier(0);  // bound live ranges: one point per window
-          }
-#endif
         }
       }
     }
-#if TREX_CONTACT_REPLICATED
 #pragma unroll
     for (int c = 0; c < MAXC; c++)
       if (ls == c) { c_lam[0] = lam[c][0]; c_lam[1] = lam[c][1]; c_lam[2] = lam[c][2]; }
-#endif
 #if TREX_STAMPS
     if (DEBUG && args.debug && blockIdx.x == 0 && threadIdx.x == 0) {
       args.debug[3000 + 16 * sub + 14] = (float)acc_joint;
