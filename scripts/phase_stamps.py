@@ -49,6 +49,8 @@ def main():
     for name, c in zip(NAMES, tot):
         print("%-32s %9.0f cycles  %5.1f %%" % (name, c, 100 * c / tot.sum()))
     print("%-32s %9.0f cycles per env-step (5 substeps)" % ("total", tot.sum()))
+    sub2 = d[3100:3140].reshape(5, 8)[:, :5]
+    print("contact generation marks (cycles after the previous phase stamp; last step, substeps x [scan, large, K, fast path, end]):\n", sub2)
     print("inside PGS: joint rows (limits+motors) %.0f cycles = %.1f per motor row; contact rows %.0f cycles = %.1f per row (3 x %d); limit mask %s"
           % (joint / 10, joint / 10 / (300 * 25), tot[12] - joint / 10, (tot[12] - joint / 10) / (300 * 3 * cnt[0].item() + 1e-9), cnt[0].item(), limw))
 

@@ -50,8 +50,17 @@
     stamp_last = _t;                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                    \
   } while (0)
+#define STAMP2(i)                                                                         \
+  do {                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    const unsigned long long _t = __builtin_amdgcn_s_memtime();                           \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                                   \
+    if (DEBUG && args.debug && blockIdx.x == 0 && threadIdx.x == 0) args.debug[3100 + 8 * sub + (i)] = (float)(_t - stamp_last); \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+  } while (0)
 #else
 #define STAMP(i) do {} while (0)
+#define STAMP2(i) do {} while (0)
 #endif
 
 namespace {
@@ -790,10 +799,41 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       // a sphere for the long bones): z_centre - sum_k |R_zk| half_k
       const float reach = fabsf(R[6]) * boxh[0] + fabsf(R[7]) * boxh[1] + fabsf(R[8]) * boxh[2];
       const bool near = is_body && hull_v1 > hull_v0 && (pos[2] + r[2] + sc[2] - reach - floor_z < margin);
-      unsigned near_mask = tballot(near);
       unsigned active_mask = 0u;
       float a_x[3] = {0.f, 0.f, 0.f}, a_d = 0.f;   // lane b: deepest candidate of body b
       int a_v = -1;
+      // (i) small hulls (<= 96 vertices: every foot, shank, neck and tail segment): the BODY LANE scans its
+      // own vertices serially with its own R, r - all near bodies in parallel, no shuffles, no reductions.
+      constexpr int SMALL_HULL = 96;
+      const int nverts = hull_v1 - hull_v0;
+      const bool small = near && nverts <= SMALL_HULL;
+      if (wave_any(small)) {
+        float bs = -3.0e38f;
+        constexpr int UN = 8;   // 8 independent 16-B loads in flight per lane (128 contiguous bytes)
+        for (int i0 = 0; wave_any(small && i0 < nverts); i0 += UN) {
+          float4 h[UN];
+#pragma unroll
+          for (int u = 0; u < UN; u++) {
+            const int i = min(i0 + u, nverts - 1);
+            h[u] = args.arr.hull[hull_v0 + (small ? max(i, 0) : 0)];
+          }
+#pragma unroll
+          for (int u = 0; u < UN; u++) {
+            const int i = i0 + u;
+            const float hv[3] = {h[u].x, h[u].y, h[u].z};
+            float w[3];
+            matvec3(R, hv, w);
+            const float dd = pos[2] + r[2] + w[2] - floor_z;
+            if (small && i < nverts && dd < margin && -dd > bs) {
+              bs = -dd; a_v = hull_v0 + i; a_x[0] = r[0] + w[0]; a_x[1] = r[1] + w[1]; a_x[2] = r[2] + w[2]; a_d = dd;
+            }
+          }
+        }
+        active_mask |= tballot(small && a_v >= 0);
+      }
+      STAMP2(0);
+      // (ii) large hulls (cranium, pelvis+ribcage): the team strides over the vertices together
+      unsigned near_mask = tballot(near && !small);
       while (wave_any(near_mask != 0u)) {
         const bool valid = near_mask != 0u;
         const int b = valid ? (__ffs(near_mask) - 1) : 0;
@@ -823,9 +863,23 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
           if (lane == b) { a_x[0] = wx; a_x[1] = wy; a_x[2] = wz; a_d = -bs; a_v = bi; }
         }
       }
+      STAMP2(1);
       const int n_active = __popc(active_mask);
       int K = n_active > 0 ? maxc / n_active : 0;
       K = K > 4 ? 4 : (K < 1 ? 1 : K);
+      STAMP2(2);
+      if (!wave_any(n_active > 0 && K >= 2)) {
+        // fast path (one point per touching body in both envs of the wave - the standing case): contact
+        // slot c takes the c-th touching body; every lane finds its body and gathers its point at once
+        unsigned m = active_mask;
+        for (int i = 0; i < lane && m != 0u; i++) m &= m - 1u;
+        nc = min(n_active, maxc);
+        const int bsrc = m != 0u ? (__ffs(m) - 1) : 0;
+        const float gx = tshfl(a_x[0], bsrc), gy = tshfl(a_x[1], bsrc), gz = tshfl(a_x[2], bsrc), gd = tshfl(a_d, bsrc);
+        if (lane < nc) { cbody = bsrc; cx[0] = gx; cx[1] = gy; cx[2] = gz; cdist = gd; }
+        active_mask = 0u;
+      }
+      STAMP2(3);
       while (wave_any(active_mask != 0u)) {
         const bool valid = active_mask != 0u;
         const int b = valid ? (__ffs(active_mask) - 1) : 0;
@@ -898,6 +952,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       }
     }
 
+    STAMP2(4);
     STAMP(8);
     // ---- contact rows: lane c owns point c and walks its body's chain for the three directions
     //      (normal z, friction x, friction y); everything below is per lane, no reductions.
