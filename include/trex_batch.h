@@ -99,7 +99,8 @@ int trex_batch_reset(TrexBatch *batch, const uint8_t *mask_dev, float *obs_out_d
  *   actions_dev   [N, J]  f32 device, joint targets in observation order
  *   obs_dev       [N, 3J] f32 device: q, qd, appliedJointMotorTorque (trex_robot.py:365)
  *   reward_dev    [N]     f32 device (trex_env.py:192)
- *   done_dev      [N]     u8 device, always 0 (trex_env.py:183-184)
+ *   done_dev      [N]     u8 device, 0 (trex_env.py:183-184) - except 1 for an env whose state became
+ *                         non-finite: it is put back on the start pose and reports reward 0 (containment)
  *   penalties_dev [N, 3]  f32 device, nullable: lifting_com, station_keeping, energy
  *                         (the three values logged at trex_env.py:193-195) */
 int trex_batch_step(TrexBatch *batch, const float *actions_dev, float *obs_dev, float *reward_dev,

@@ -343,6 +343,33 @@ def test_time_limit_auto_reset():
     assert not done.any()
 
 
+def test_non_finite_env_is_contained():
+    """A NaN / Inf state resets that env (done = 1, reward 0) and leaves every other env - including
+    its wave partner - bitwise untouched."""
+    v = make_vec(6)
+    v.reset()
+    a = torch.zeros(6, 25, device=DEV)
+    for _ in range(3):
+        v.step_tensor(a)
+    st = v.get_state().clone()
+    ref = make_vec(6)
+    ref.reset()
+    ref.set_state(st)
+    bad = st.clone()
+    bad[2, 40] = float("nan")      # env 2 shares a wave with env 3
+    bad[5, 2] = float("inf")
+    v.set_state(bad)
+    o1, r1, d1 = v.step_tensor(a)
+    o0, r0, d0 = ref.step_tensor(a)
+    assert d1.tolist() == [False, False, True, False, False, True]
+    assert torch.isfinite(o1).all() and torch.isfinite(r1).all() and torch.isfinite(v.get_state()).all()
+    keep = [0, 1, 3, 4]
+    assert (o1[keep] == o0[keep]).all() and (r1[keep] == r0[keep]).all()
+    assert r1[2].item() == 0.0 and (v.get_state()[2, :3].cpu() == torch.tensor([0.0, 0.0, 3.0])).all()
+    o2, r2, d2 = v.step_tensor(a)
+    assert not d2.any()
+
+
 def test_error_paths(capi):
     v = make_vec(2)
     with pytest.raises(ValueError):

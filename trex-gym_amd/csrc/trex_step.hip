@@ -351,6 +351,12 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
     mtau = args.arr.tau[env * TL + lane];
     motors_on = RESET ? (args.arr.motors_on[env] != 0) : true;
   }
+  // non-finite input state (checked here as well as after the step: fminf/fmaxf clamps launder NaNs)
+  bool bad = !(fabsf(q) < 3.0e38f) || !(fabsf(qd) < 3.0e38f);
+#pragma unroll
+  for (int k = 0; k < 3; k++) bad |= !(fabsf(pos[k]) < 3.0e38f) || !(fabsf(bv[k]) < 3.0e38f) || !(fabsf(bw[k]) < 3.0e38f);
+#pragma unroll
+  for (int k = 0; k < 4; k++) bad |= !(fabsf(quat[k]) < 3.0e38f);
   float target = 0.f;
   if (!RESET && is_joint) {
     const float a = args.actions[env * nj + M->obs_slot[lane]];
@@ -1278,6 +1284,22 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
   const float energy = args.w_energy * power;
 
   if (!env_ok) return;
+  // ---- failure containment (no reference counterpart): an env whose state stopped being
+  // finite is put back on the start pose with zero velocities and reports done = 1 once, with a finite
+  // reward of 0; it never poisons its wave partner (every cross-lane exchange stays inside the team).
+  bad |= !(fabsf(q) < 3.0e38f) || !(fabsf(qd) < 3.0e38f);
+#pragma unroll
+  for (int k = 0; k < 3; k++) bad |= !(fabsf(pos[k]) < 3.0e38f) || !(fabsf(bv[k]) < 3.0e38f) || !(fabsf(bw[k]) < 3.0e38f);
+#pragma unroll
+  for (int k = 0; k < 4; k++) bad |= !(fabsf(quat[k]) < 3.0e38f);
+  const bool env_bad = tballot(bad) != 0u;
+  if (env_bad) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { pos[k] = M->base_pos0[k]; bv[k] = 0.f; bw[k] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) quat[k] = M->base_quat0[k];
+    q = M->q_start[lane]; qd = 0.f; mtau = 0.f;
+  }
   // ---- write back
   const bool store_state = RESET ? do_reset : true;
   if (store_state) {
@@ -1299,10 +1321,11 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
     o[obs_slot] = q; o[nj + obs_slot] = qd; o[2 * nj + obs_slot] = mtau;
   }
   if (lane == 0) {
-    if (args.reward) args.reward[env] = -lift - drift - energy;
-    if (args.done) args.done[env] = 0;  // should_terminate() is constant False, trex_env.py:183-184
+    if (args.reward) args.reward[env] = env_bad ? 0.f : -lift - drift - energy;
+    if (args.done) args.done[env] = env_bad ? 1 : 0;  // should_terminate() is constant False, trex_env.py:183-184
     if (args.penalties) {
-      args.penalties[env * 3 + 0] = lift; args.penalties[env * 3 + 1] = drift; args.penalties[env * 3 + 2] = energy;
+      args.penalties[env * 3 + 0] = env_bad ? 0.f : lift; args.penalties[env * 3 + 1] = env_bad ? 0.f : drift;
+      args.penalties[env * 3 + 2] = env_bad ? 0.f : energy;
     }
   }
 }
