@@ -77,7 +77,7 @@ int trex_model_get_param(const TrexModel *model, const char *name, double *value
  * element count (or a negative error). Names: "parent" "depth" "joint_axis" "joint_pos" "joint_rot"
  * "q_lower" "q_upper" "joint_damping" "mass" "com" "inertia" "obs_order" "head_body" "head_point"
  * "hull_xyz" "hull_start" "sphere_center" "sphere_radius" "q_start" "base_start_pos"
- * "base_start_quat" "revolute_joint_indices". */
+ * "base_start_quat" "revolute_joint_indices" "link_body" "link_tf" (12 per link: R row-major, t). */
 int trex_model_get_array(const TrexModel *model, const char *name, double *out, int capacity);
 
 /* ---- batch: N independent env copies resident on one GPU ---- */
@@ -117,6 +117,14 @@ int trex_batch_set_motors_enabled(TrexBatch *batch, int enabled, void *stream);
 
 /* world position of the head link COM, [N,3] (trex_robot.py:330-335). */
 int trex_batch_head_position(TrexBatch *batch, float *out_dev, void *stream);
+
+/* Rollout export for rendering (the step after the path: trex_env.py:156-181, trex_train.py:126-136):
+ * world pose of EVERY URDF link frame (133 for trex.urdf, document order) as [N, L, 7] f32 device =
+ * position xyz + quaternion xyzw - what getLinkState(...)[4:6] returns per link [EXT]. A renderer
+ * composes it with the <visual><origin> of each mesh. */
+int trex_model_num_links(const TrexModel *model);
+int trex_model_link_info(const TrexModel *model, int link, const char **name, int *body);
+int trex_batch_link_transforms(TrexBatch *batch, float *out_dev, void *stream);
 
 /* domain randomisation (BASELINE config 5; no reference counterpart): per-env mass scale of each
  * moving body [N, num_bodies] and per-env friction coefficient [N]; either may be NULL. */

@@ -306,6 +306,14 @@ def compile_model(urdf_path, collisions_dir=None, start_configuration=None):
             sphere_c[i] = 0.5 * (lo + hi)
             sphere_r[i] = np.sqrt(((v - sphere_c[i]) ** 2).sum(1).max())
         hull_start.append(hull_start[-1] + (len(verts) and sum(len(x) for x in verts)))
+    # every URDF link (document order): body it was merged into, link frame in that body's frame
+    m["link_names"] = [l["name"] for l in links]
+    lb, lR, lt = {}, {}, {}
+    for i, b in enumerate(bodies):
+        for ln, tf in b["members"]:
+            lb[ln], lR[ln], lt[ln] = i, tf.R.reshape(9), tf.t
+    m["link_body"] = np.array([lb[n] for n in m["link_names"]], np.int32)
+    m["link_tf"] = np.array([np.concatenate([lR[n], lt[n]]) for n in m["link_names"]])
     m["hull_xyz"] = np.concatenate(hull_xyz) if hull_xyz else np.zeros((0, 3))
     m["hull_start"] = np.array(hull_start, np.int32)
     m["sphere_center"], m["sphere_radius"] = sphere_c, sphere_r

@@ -37,12 +37,13 @@ def test_model_matches_oracle_model(capi, model):
     for name in ["parent", "depth", "joint_axis", "joint_pos", "joint_rot", "q_lower", "q_upper",
                  "joint_damping", "mass", "com", "inertia", "obs_order", "head_point", "hull_xyz",
                  "hull_start", "sphere_center", "sphere_radius", "q_start", "base_start_pos",
-                 "base_start_quat", "revolute_joint_indices"]:
+                 "base_start_quat", "revolute_joint_indices", "link_body", "link_tf"]:
         got = m.array(name)
         want = np.asarray(model[name], float).reshape(-1)
         assert got.shape == want.shape, name
         np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12, err_msg=name)
     assert int(m.array("head_body")[0]) == model["head_body"]
+    assert [n for n, _ in m.links()] == model["link_names"] and len(m.links()) == 133
 
 
 @pytest.mark.skipif(not os.path.isdir(REFERENCE_ROOT), reason="reference only in the authoring container")

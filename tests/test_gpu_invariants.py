@@ -100,3 +100,49 @@ def test_double_pendulum_model_through_the_same_kernel(tmp_path):
     np.testing.assert_allclose(g[0, 4:], o[4:], atol=2e-3 * (np.abs(o[4:]).max() + 1))
     # the position motor pulls the joints toward their targets
     assert abs(g[0, 0] - 0.2) < abs(0.7 - 0.2) and abs(g[0, 1] + 0.4) < 0.4
+
+
+def test_link_transforms_match_reference_fk_and_oracle(model, oracle64):
+    """Rollout export: world pose of all 133 URDF link frames.
+    (a) start pose with the ROOT LINK frame at identity == the fixture computed by the reference's own
+        Transform algebra (tests/golden/urdf_reference.json, scripts/make_golden.py);
+    (b) random states == oracle body poses composed with the link-in-body transforms."""
+    import json
+    import os
+    from oracle import trex_model as tm
+    from trex_gym.vec_env import TrexVecEnv
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "urdf_reference.json")))
+    joints, links = tm.parse_urdf(ASSET_URDF)
+    root = [l for l in links if l["name"] == model["body_names"][0]][0]
+    n = 5
+    st = np.zeros((n, 63), np.float32)
+    st[0, 0:3] = root["inertial_origin"].t
+    st[0, 3:7] = tm.matrix_to_quat(root["inertial_origin"].R)
+    st[0, 13:38] = model["q_start"][model["obs_order"]]
+    rng = np.random.default_rng(3)
+    lo, hi = model["q_lower"][model["obs_order"]], model["q_upper"][model["obs_order"]]
+    for e in range(1, n):
+        st[e, 0:3] = rng.normal(size=3) + [0, 0, 4]
+        q = rng.normal(size=4); st[e, 3:7] = q / np.linalg.norm(q)
+        st[e, 13:38] = rng.uniform(lo, hi)
+    v = TrexVecEnv(n, urdf_path=ASSET_URDF, device=DEV)
+    v.reset()
+    v.set_state(torch.tensor(st))
+    out = v.link_transforms().cpu().numpy()
+    names = [nm for nm, _ in v.model.links()]
+    assert out.shape == (n, 133, 7) and names == model["link_names"]
+    for k, nm in enumerate(names):                       # (a) the reference's FK, every link
+        g = gold["fk_start_pose"][nm]
+        np.testing.assert_allclose(out[0, k, :3], g["xyz"], atol=5e-6, err_msg=nm)
+        np.testing.assert_allclose(tm.quat_to_matrix(out[0, k, 3:]), tm.quat_to_matrix(g["quat_xyzw"]), atol=5e-6, err_msg=nm)
+    for e in range(1, n):                                # (b) oracle composition
+        s = oracle64.new_state()
+        oracle64.set_state(s, st[e].astype(np.float64))
+        pos, rot = oracle64.body_poses(s)
+        for k in range(133):
+            b = model["link_body"][k]
+            R = rot[b] @ model["link_tf"][k][:9].reshape(3, 3)
+            p = pos[b] + rot[b] @ model["link_tf"][k][9:]
+            np.testing.assert_allclose(out[e, k, :3], p, atol=2e-5)
+            np.testing.assert_allclose(tm.quat_to_matrix(out[e, k, 3:]), R, atol=2e-5)
+            assert out[e, k, 6] >= 0 and abs(np.linalg.norm(out[e, k, 3:]) - 1) < 1e-5

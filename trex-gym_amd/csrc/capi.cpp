@@ -19,6 +19,7 @@ hipError_t trex_launch_reset(const TrexDeviceModel *, TrexBatchArrays, int, cons
                              float, float *, hipStream_t);
 hipError_t trex_launch_pack_state(const TrexDeviceModel *, TrexBatchArrays, int, float *, int, hipStream_t);
 hipError_t trex_launch_head(const TrexDeviceModel *, TrexBatchArrays, int, float *, hipStream_t);
+hipError_t trex_launch_link_transforms(const TrexDeviceModel *, TrexBatchArrays, int, float *, hipStream_t);
 hipError_t trex_launch_fill(float *, float, int, hipStream_t);
 hipError_t trex_launch_fill_u8(uint8_t *, uint8_t, int, hipStream_t);
 hipError_t trex_launch_copy_mass_scale(const float *, float *, int, int, hipStream_t);
@@ -227,6 +228,8 @@ int trex_model_get_array(const TrexModel *m, const char *name, double *out, int 
   else if (n == "obs_order") v.assign(h.obs_order.begin(), h.obs_order.end());
   else if (n == "revolute_joint_indices") v.assign(h.revolute_joint_indices.begin(), h.revolute_joint_indices.end());
   else if (n == "head_body") v = {(double)h.head_body};
+  else if (n == "link_body") v.assign(h.link_body.begin(), h.link_body.end());
+  else if (n == "link_tf") { for (auto &t : h.link_tf) { v.insert(v.end(), t.R.m, t.R.m + 9); v.push_back(t.t.x); v.push_back(t.t.y); v.push_back(t.t.z); } }
   else if (n == "head_point") v = {h.head_point.x, h.head_point.y, h.head_point.z};
   else if (n == "hull_xyz") push3(h.hull_xyz);
   else if (n == "hull_start") v.assign(h.hull_start.begin(), h.hull_start.end());
@@ -279,10 +282,23 @@ int trex_batch_create(const TrexModel *model, int num_envs, int device, TrexBatc
   A(n * sizeof(float), (void **)&b->arr.normal_impulse);
   size_t nv = model->host.hull_xyz.size();
   A((nv ? nv : 1) * sizeof(float4), (void **)&b->arr.hull);
+  const size_t nl = model->host.link_names.size();
+  int *link_body_dev = nullptr;
+  float *link_tf_dev = nullptr;
+  A(nl * sizeof(int), (void **)&link_body_dev);
+  A(nl * 12 * sizeof(float), (void **)&link_tf_dev);
   if (r != hipSuccess) { cleanup(); return hip_fail(r, "hipMalloc"); }
   std::vector<float4> hull(nv ? nv : 1);
   for (size_t i = 0; i < nv; i++) hull[i] = make_float4((float)model->host.hull_xyz[i].x, (float)model->host.hull_xyz[i].y, (float)model->host.hull_xyz[i].z, 0.f);
-  r = hipMemcpy(b->dmodel, &dm, sizeof dm, hipMemcpyHostToDevice);
+  std::vector<float> ltf(nl * 12);
+  for (size_t l = 0; l < nl; l++) {
+    for (int k = 0; k < 9; k++) ltf[12 * l + k] = (float)model->host.link_tf[l].R.m[k];
+    ltf[12 * l + 9] = (float)model->host.link_tf[l].t.x; ltf[12 * l + 10] = (float)model->host.link_tf[l].t.y; ltf[12 * l + 11] = (float)model->host.link_tf[l].t.z;
+  }
+  b->arr.num_links = (int)nl; b->arr.link_body = link_body_dev; b->arr.link_tf = link_tf_dev;
+  r = hipMemcpy(link_body_dev, model->host.link_body.data(), nl * sizeof(int), hipMemcpyHostToDevice);
+  if (r == hipSuccess) r = hipMemcpy(link_tf_dev, ltf.data(), ltf.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (r == hipSuccess) r = hipMemcpy(b->dmodel, &dm, sizeof dm, hipMemcpyHostToDevice);
   if (r == hipSuccess) r = hipMemcpy(b->arr.hull, hull.data(), hull.size() * sizeof(float4), hipMemcpyHostToDevice);
   if (r == hipSuccess) r = trex_launch_fill(b->arr.mass_scale, 1.0f, num_envs * TREX_TL, nullptr);
   if (r == hipSuccess) r = trex_launch_fill(b->arr.friction, (float)model->host.prm.friction, num_envs, nullptr);
@@ -361,6 +377,22 @@ int trex_batch_head_position(TrexBatch *b, float *out_dev, void *stream) {
   if (!out_dev) return fail(TREX_E_INVALID, "out is null");
   DeviceGuard guard(b->device);
   HIP_TRY(trex_launch_head(b->dmodel, b->arr, b->n, out_dev, (hipStream_t)stream));
+  return TREX_OK;
+}
+
+int trex_model_num_links(const TrexModel *m) { return m ? (int)m->host.link_names.size() : fail(TREX_E_INVALID, "null model"); }
+int trex_model_link_info(const TrexModel *m, int link, const char **name, int *body) {
+  if (!m) return fail(TREX_E_INVALID, "null model");
+  if (link < 0 || link >= (int)m->host.link_names.size()) return fail(TREX_E_INVALID, "link index out of range");
+  if (name) *name = m->host.link_names[link].c_str();
+  if (body) *body = m->host.link_body[link];
+  return TREX_OK;
+}
+int trex_batch_link_transforms(TrexBatch *b, float *out_dev, void *stream) {
+  if (check_batch(b)) return TREX_E_INVALID;
+  if (!out_dev) return fail(TREX_E_INVALID, "out is null");
+  DeviceGuard guard(b->device);
+  HIP_TRY(trex_launch_link_transforms(b->dmodel, b->arr, b->n, out_dev, (hipStream_t)stream));
   return TREX_OK;
 }
 

@@ -420,6 +420,10 @@ HostModel load_model(const std::string &urdf_path, const char *collisions_dir, i
       m.hull_start.push_back((int)m.hull_xyz.size());
     }
     if (m.head_body < 0) { m.head_body = 0; m.head_point = m.com[0]; }  // generic URDF: reward point = base COM
+    m.link_names.resize(links.size()); m.link_body.assign(links.size(), 0); m.link_tf.resize(links.size());
+    for (size_t l = 0; l < links.size(); l++) m.link_names[l] = links[l].name;
+    for (int i = 0; i < nb; i++)
+      for (auto &[li, tf] : bodies[i].members) { m.link_body[li] = i; m.link_tf[li] = tf; }
 
     // observation order = revolute joint names sorted (trex_robot.py:311-314)
     std::vector<std::pair<std::string, int>> named;

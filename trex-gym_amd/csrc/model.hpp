@@ -50,6 +50,10 @@ struct HostModel {
   std::vector<std::string> obs_joint_names;
   int head_body = -1;
   Vec3 head_point;
+  // every URDF link (document order): the body it was merged into and its frame in that body's frame
+  std::vector<std::string> link_names;
+  std::vector<int> link_body;
+  std::vector<Tf> link_tf;
   std::vector<Vec3> hull_xyz;
   std::vector<int> hull_start;
   double total_mass = 0, total_mass_excluding_base = 0;

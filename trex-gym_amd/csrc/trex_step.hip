@@ -1391,6 +1391,69 @@ __global__ void trex_head_kernel(KernelArgs args, float *out) {
   for (int k = 0; k < 3; k++) out[env * 3 + k] = b[k] + r[k] + o[k];
 }
 
+// Rollout export: world pose of every URDF link. One 64-thread block per env: lanes < nb walk their
+// body's chain from the base (<= 6 hinges) and park R, p in LDS; then the block strides over the links.
+__global__ __launch_bounds__(64) void trex_link_transforms_kernel(KernelArgs args, float *out) {
+  __shared__ float bodyR[TL][9], bodyP[TL][3];
+  const int env = blockIdx.x;
+  const TrexDeviceModel *M = args.model;
+  const int t = threadIdx.x;
+  const float *b = args.arr.base + env * 16;
+  if (t < M->nb) {
+    const float quat[4] = {b[3], b[4], b[5], b[6]};
+    float R[9], p[3] = {b[0], b[1], b[2]};
+    quat_to_mat(quat, R);
+    int chain[MAXD + 1], n = 0;
+    for (int i = t; i > 0; i = M->parent[i]) chain[n++] = i;
+    for (int k = n - 1; k >= 0; k--) {
+      const int i = chain[k];
+      const float ax[3] = {M->axis[0][i], M->axis[1][i], M->axis[2][i]}, jp[3] = {M->jpos[0][i], M->jpos[1][i], M->jpos[2][i]};
+      float jr[9], rq[9], tmp[9], o[3];
+      for (int c = 0; c < 9; c++) jr[c] = M->jrot[c][i];
+      const float q = args.arr.q[env * TL + i];
+      const float c = cosf(q), s = sinf(q), tt = 1.f - c;
+      rq[0] = tt * ax[0] * ax[0] + c;         rq[1] = tt * ax[0] * ax[1] - s * ax[2]; rq[2] = tt * ax[0] * ax[2] + s * ax[1];
+      rq[3] = tt * ax[0] * ax[1] + s * ax[2]; rq[4] = tt * ax[1] * ax[1] + c;         rq[5] = tt * ax[1] * ax[2] - s * ax[0];
+      rq[6] = tt * ax[0] * ax[2] - s * ax[1]; rq[7] = tt * ax[1] * ax[2] + s * ax[0]; rq[8] = tt * ax[2] * ax[2] + c;
+      matvec3(R, jp, o);
+      for (int k2 = 0; k2 < 3; k2++) p[k2] += o[k2];
+      matmul3(R, jr, tmp);
+      matmul3(tmp, rq, R);
+    }
+    for (int c = 0; c < 9; c++) bodyR[t][c] = R[c];
+    for (int c = 0; c < 3; c++) bodyP[t][c] = p[c];
+  }
+  __syncthreads();
+  const int L = args.arr.num_links;
+  for (int l = t; l < L; l += blockDim.x) {
+    const int body = args.arr.link_body[l];
+    const float *tf = args.arr.link_tf + 12 * l;
+    float R[9], o[3];
+    matmul3(bodyR[body], tf, R);
+    matvec3(bodyR[body], tf + 9, o);
+    float *w = out + ((size_t)env * L + l) * 7;
+    for (int c = 0; c < 3; c++) w[c] = bodyP[body][c] + o[c];
+    // rotation matrix -> quaternion xyzw (w >= 0)
+    float qx, qy, qz, qw;
+    const float tr = R[0] + R[4] + R[8];
+    if (tr > 0.f) {
+      const float s = sqrtf(tr + 1.f) * 2.f;
+      qw = 0.25f * s; qx = (R[7] - R[5]) / s; qy = (R[2] - R[6]) / s; qz = (R[3] - R[1]) / s;
+    } else if (R[0] >= R[4] && R[0] >= R[8]) {
+      const float s = sqrtf(1.f + R[0] - R[4] - R[8]) * 2.f;
+      qw = (R[7] - R[5]) / s; qx = 0.25f * s; qy = (R[1] + R[3]) / s; qz = (R[2] + R[6]) / s;
+    } else if (R[4] >= R[8]) {
+      const float s = sqrtf(1.f + R[4] - R[0] - R[8]) * 2.f;
+      qw = (R[2] - R[6]) / s; qx = (R[1] + R[3]) / s; qy = 0.25f * s; qz = (R[5] + R[7]) / s;
+    } else {
+      const float s = sqrtf(1.f + R[8] - R[0] - R[4]) * 2.f;
+      qw = (R[3] - R[1]) / s; qx = (R[2] + R[6]) / s; qy = (R[5] + R[7]) / s; qz = 0.25f * s;
+    }
+    const float sg = qw < 0.f ? -1.f : 1.f;
+    w[3] = sg * qx; w[4] = sg * qy; w[5] = sg * qz; w[6] = sg * qw;
+  }
+}
+
 __global__ void trex_fill_kernel(float *p, float v, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -1435,6 +1498,12 @@ hipError_t trex_launch_pack_state(const TrexDeviceModel *model, TrexBatchArrays 
 hipError_t trex_launch_head(const TrexDeviceModel *model, TrexBatchArrays arr, int n, float *out, hipStream_t stream) {
   KernelArgs a{model, arr, n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, nullptr};
   hipLaunchKernelGGL(trex_head_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a, out);
+  return hipGetLastError();
+}
+
+hipError_t trex_launch_link_transforms(const TrexDeviceModel *model, TrexBatchArrays arr, int n, float *out, hipStream_t stream) {
+  KernelArgs a{model, arr, n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, nullptr};
+  hipLaunchKernelGGL(trex_link_transforms_kernel, dim3(n), dim3(64), 0, stream, a, out);
   return hipGetLastError();
 }
 

@@ -34,6 +34,7 @@ SYMBOLS = [
     "trex_batch_reset", "trex_batch_step", "trex_batch_get_state", "trex_batch_set_state",
     "trex_batch_set_motors_enabled", "trex_batch_head_position", "trex_batch_set_domain",
     "trex_batch_contact_stats", "trex_batch_debug_step", "trex_batch_launch_info", "trex_batch_time_steps",
+    "trex_model_num_links", "trex_model_link_info", "trex_batch_link_transforms",
 ]
 
 _vp = C.c_void_p
@@ -66,6 +67,9 @@ lib.trex_batch_set_state.argtypes = [_vp, _vp, _vp]
 lib.trex_batch_set_motors_enabled.argtypes = [_vp, C.c_int, _vp]
 lib.trex_batch_head_position.argtypes = [_vp, _vp, _vp]
 lib.trex_batch_set_domain.argtypes = [_vp, _vp, _vp, _vp]
+lib.trex_model_num_links.argtypes = [_vp]
+lib.trex_model_link_info.argtypes = [_vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
+lib.trex_batch_link_transforms.argtypes = [_vp, _vp, _vp]
 lib.trex_batch_contact_stats.argtypes = [_vp, _vp, _vp, _vp]
 lib.trex_batch_launch_info.argtypes = [_vp] + [C.POINTER(C.c_int)] * 4
 lib.trex_batch_time_steps.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, C.POINTER(C.c_float)]
@@ -124,6 +128,15 @@ class Model:
                 self.h = None
         except Exception:
             pass
+
+    def links(self):
+        """[(name, body index)] of every URDF link, document order."""
+        out = []
+        for k in range(lib.trex_model_num_links(self.h)):
+            name, body = C.c_char_p(), C.c_int()
+            check(lib.trex_model_link_info(self.h, k, C.byref(name), C.byref(body)))
+            out.append((name.value.decode(), body.value))
+        return out
 
     def total_mass(self, include_base_link=False):
         return lib.trex_model_total_mass(self.h, int(include_base_link))
@@ -206,6 +219,9 @@ class Batch:
 
     def head_position(self, out, stream=None):
         check(lib.trex_batch_head_position(self.h, _ptr(out), self._stream(stream)))
+
+    def link_transforms(self, out, stream=None):
+        check(lib.trex_batch_link_transforms(self.h, _ptr(out), self._stream(stream)))
 
     def set_domain(self, mass_scale=None, friction=None, stream=None):
         check(lib.trex_batch_set_domain(self.h, _ptr(mass_scale), _ptr(friction), self._stream(stream)))

@@ -141,6 +141,14 @@ class TrexVecEnv:
         self.batch.head_position(out)
         return out
 
+    def link_transforms(self):
+        """World pose of every URDF link frame, [n, L, 7] = xyz + quaternion xyzw (rollout export for
+        rendering, the step after the path: trex_env.py:156-181)."""
+        L = len(self.model.links())
+        out = torch.empty(self.num_envs, L, 7, device=self.device)
+        self.batch.link_transforms(out)
+        return out
+
     def set_domain(self, mass_scale=None, friction=None):
         """Per-env domain randomisation (BASELINE config 5): mass_scale [n, num_bodies], friction [n]."""
         if mass_scale is not None:
