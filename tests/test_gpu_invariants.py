@@ -146,3 +146,36 @@ def test_link_transforms_match_reference_fk_and_oracle(model, oracle64):
             np.testing.assert_allclose(out[e, k, :3], p, atol=2e-5)
             np.testing.assert_allclose(tm.quat_to_matrix(out[e, k, 3:]), R, atol=2e-5)
             assert out[e, k, 6] >= 0 and abs(np.linalg.norm(out[e, k, 3:]) - 1) < 1e-5
+
+
+def test_step_is_graph_capturable_and_stream_ordered():
+    """The launch path allocates nothing and never syncs, so a step can be captured in a HIP graph on
+    a side stream and replayed; replay == eager, bitwise."""
+    from trex_gym.vec_env import TrexVecEnv
+    n = 512
+    a = torch.zeros(n, 25, device=DEV)
+    eager = TrexVecEnv(n, urdf_path=ASSET_URDF, device=DEV)
+    graph = TrexVecEnv(n, urdf_path=ASSET_URDF, device=DEV)
+    eager.reset_tensor(); graph.reset_tensor()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):            # captures on a side stream; _capi passes torch's current stream down
+        graph.batch.step(a, graph.obs, graph.rew, graph.done, graph.penalties)
+    for t in range(12):
+        a.copy_(0.3 * torch.sin(torch.arange(25, device=DEV) + t).expand(n, 25))
+        g.replay()
+        eager.batch.step(a, eager.obs, eager.rew, eager.done, eager.penalties)
+    torch.cuda.synchronize()
+    assert (graph.obs == eager.obs).all() and (graph.rew == eager.rew).all()
+    assert (graph.get_state() == eager.get_state()).all()
+
+
+def test_launch_info_and_event_timing(capi=None):
+    from trex_gym.vec_env import TrexVecEnv
+    v = TrexVecEnv(1000, urdf_path=ASSET_URDF, device=DEV)
+    v.reset_tensor()
+    info = v.batch.launch_info()
+    assert info["grid"] == 500 and info["block"] == 64 and info["alg_bytes_per_env_step"] == 912
+    assert 0 < info["lds_bytes"] <= 20 * 1024          # 8 workgroups per CU must fit the 160 KB of LDS
+    ms = v.batch.time_steps(torch.zeros(1000, 25, device=DEV), v.obs, v.rew, v.done, 5)
+    assert 0.05 < ms < 50
