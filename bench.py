@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--collision", choices=["hulls", "primitives"], default="hulls",
+                    help="primitives: capsules/spheres fitted to the hulls (148 points instead of 2181 vertices); not the headline config")
     ap.add_argument("--domain-rand", action="store_true",
                     help="BASELINE config 5: per-env body-mass scale U(0.8,1.2) and friction U(0.5,1.25), seed 1")
     ap.add_argument("--action-scale", type=float, default=1.0,
@@ -115,7 +117,9 @@ def main():
 
     n_global = args.envs_per_gpu * world
     overrides = {k: float(v) for k, v in (p.split("=") for p in args.param)}
-    env = TrexVecEnv(n_global, device=dev, rank=rank, world_size=world, params=overrides)
+    env = TrexVecEnv(n_global, device=dev, rank=rank, world_size=world, params=overrides, collision=args.collision)
+    if args.collision != "hulls":
+        overrides = dict(overrides, collision=args.collision)
     n_local = env.num_envs
     if args.domain_rand:
         g = torch.Generator(device=dev).manual_seed(1)

@@ -66,6 +66,12 @@ int trex_model_joint_info(const TrexModel *model, int k, const char **name, int 
 int trex_model_set_start_angle(TrexModel *model, const char *joint_name, double angle);
 int trex_model_set_start_pose(TrexModel *model, const double xyz[3], const double rpy[3]); /* trex_env.py:105-106 */
 
+/* Collision primitives (the step before the path): replace every convex hull by capsules /
+ * spheres fitted as the reference's tools/mesh_primitives.py:323-402 does (PCA box -> capsule, octant
+ * subdivision while radius > max_radius). Contacts are then generated from the capsule end spheres
+ * (148 points instead of 2 181 vertices for trex.urdf at max_radius 0.2). Call before trex_batch_create. */
+int trex_model_use_primitive_collision(TrexModel *model, double max_radius, int max_divisions, int min_points);
+
 /* engine parameters: "dt" "substeps" "iterations" "gravity" "motor_kp" "motor_kd" "motor_max_force"
  * "floor_z" "friction" "erp" "contact_erp" "contact_margin" "link_damping"
  * "max_coordinate_velocity" "max_contacts"  (setTimeStep / setPhysicsEngineParameter / setGravity,
@@ -76,7 +82,7 @@ int trex_model_get_param(const TrexModel *model, const char *name, double *value
 /* Introspection of the compiled model for tests: copies the named array as doubles, returns the
  * element count (or a negative error). Names: "parent" "depth" "joint_axis" "joint_pos" "joint_rot"
  * "q_lower" "q_upper" "joint_damping" "mass" "com" "inertia" "obs_order" "head_body" "head_point"
- * "hull_xyz" "hull_start" "sphere_center" "sphere_radius" "q_start" "base_start_pos"
+ * "hull_xyz" "hull_radius" "hull_group_start" "hull_start" "sphere_center" "sphere_radius" "q_start" "base_start_pos"
  * "base_start_quat" "revolute_joint_indices" "link_body" "link_tf" (12 per link: R row-major, t). */
 int trex_model_get_array(const TrexModel *model, const char *name, double *out, int capacity);
 

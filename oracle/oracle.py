@@ -65,7 +65,8 @@ class Oracle:
             C.c_int(m["nb"]), i(m["parent"]), d(m["joint_axis"]), d(m["joint_pos"]), d(m["joint_rot"]),
             d(m["q_lower"]), d(m["q_upper"]), d(m["joint_damping"]), d(m["mass"]), d(m["com"]),
             d(m["inertia"]), i(m["obs_order"]), C.c_int(m["head_body"]), d(m["head_point"]),
-            C.c_int(len(m["hull_xyz"])), d(m["hull_xyz"]), i(m["hull_start"]), d(m["sphere_center"]),
+            C.c_int(len(m["hull_xyz"])), d(m["hull_xyz"]), d(m.get("hull_radius", np.zeros(len(m["hull_xyz"])))),
+            i(m["hull_start"]), d(m["sphere_center"]),
             d(m["sphere_radius"]), d(m["q_start"]), d(m["base_start_pos"]), d(m["base_start_quat"]),
             d(prm))
         assert self.h

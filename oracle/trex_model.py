@@ -264,7 +264,7 @@ def compile_model(urdf_path, collisions_dir=None, start_configuration=None):
     m["com"] = np.zeros((nb, 3))
     m["inertia"] = np.zeros((nb, 6))  # xx xy xz yy yz zz about COM, body axes
     m["n_merged"] = np.zeros(nb, np.int32)
-    hull_xyz, hull_start = [], [0]
+    hull_xyz, hull_start, hull_groups = [], [0], [0]
     sphere_c, sphere_r = np.zeros((nb, 3)), np.zeros(nb)
     head_body, head_point = -1, np.zeros(3)
     for i, b in enumerate(bodies):
@@ -299,6 +299,7 @@ def compile_model(urdf_path, collisions_dir=None, start_configuration=None):
         for ln, tf in b["members"]:
             for v, _tag in hulls.get(ln, []):
                 verts.append(tf.apply(v))
+                hull_groups.append(hull_groups[-1] + len(v))
         if verts:
             v = np.concatenate(verts)
             hull_xyz.append(v)
@@ -316,6 +317,8 @@ def compile_model(urdf_path, collisions_dir=None, start_configuration=None):
     m["link_tf"] = np.array([np.concatenate([lR[n], lt[n]]) for n in m["link_names"]])
     m["hull_xyz"] = np.concatenate(hull_xyz) if hull_xyz else np.zeros((0, 3))
     m["hull_start"] = np.array(hull_start, np.int32)
+    m["hull_group_start"] = np.array(hull_groups, np.int32)   # one group per original convex hull
+    m["hull_radius"] = np.zeros(len(m["hull_xyz"]))           # > 0 only for fitted sphere / capsule ends
     m["sphere_center"], m["sphere_radius"] = sphere_c, sphere_r
     m["head_body"], m["head_point"] = head_body, head_point
 
@@ -343,6 +346,82 @@ def compile_model(urdf_path, collisions_dir=None, start_configuration=None):
     m["q_start"] = q0
     m["base_start_pos"] = np.array([0.0, 0.0, 3.0])  # trex_env.py:105
     m["base_start_quat"] = np.array([0.0, 0.0, 0.0, 1.0])  # rpy = 0, trex_env.py:106
+    return m
+
+
+# ---------------------------------------------------------------- collision primitives
+_OCTANTS = [(1, 1, 1), (1, -1, 1), (1, -1, -1), (1, 1, -1), (-1, 1, 1), (-1, -1, 1), (-1, -1, -1), (-1, 1, -1)]
+
+
+def _principal_box(pts):
+    """PCA-aligned bounding box as tools/mesh_primitives.py:323-344: z = dominant axis, y = second,
+    x = y x z; centre = mid-range in that frame. Axis signs are canonicalised (largest component
+    positive) so that every implementation enumerates the octants in the same order."""
+    c = pts.mean(0)
+    X = pts - c
+    u, _, _ = np.linalg.svd(X.T @ X)
+    z, y = u[:, 0].copy(), u[:, 1].copy()
+    for a in (z, y):
+        if a[np.argmax(np.abs(a))] < 0:
+            a *= -1
+    x = np.cross(y, z)
+    A = np.stack([x, y, z], 1)
+    al = X @ A
+    ctr, hwl = 0.5 * (al.max(0) + al.min(0)), al.max(0) - al.min(0)
+    return A, A @ ctr + c, hwl
+
+
+def fit_primitives(points, max_radius, max_divisions=4, min_points=4, _depth=0):
+    """Capsule / sphere fitting of the reference's tools/mesh_primitives.py:347-402
+    (get_sphere_or_capsule + subdivide_points_to_geometry), restated: radius = half the larger of the
+    two minor box extents, length = major extent - 2 radius (sphere when <= 0); split into octants of
+    the box frame while radius > max_radius. The reference keeps octants with more than 100 points
+    (dense visual meshes); the hulls have 36..255 vertices, so min_points is a parameter (default 4).
+    Returns [(p0, p1, radius)] with p0 == p1 for spheres."""
+    pts = np.asarray(points, float)
+    A, ctr, hwl = _principal_box(pts)
+    r = 0.5 * max(hwl[0], hwl[1])
+    L = hwl[2] - 2.0 * r
+    if r > max_radius and _depth < max_divisions:
+        loc = (pts - ctr) @ A
+        out = []
+        for sx, sy, sz in _OCTANTS:
+            msk = ((loc[:, 0] >= 0) == (sx > 0)) & ((loc[:, 1] >= 0) == (sy > 0)) & ((loc[:, 2] >= 0) == (sz > 0))
+            if msk.sum() > min_points:
+                out += fit_primitives(pts[msk], max_radius, max_divisions, min_points, _depth + 1)
+        return out
+    if L > 0:
+        return [(ctr - A[:, 2] * (0.5 * L), ctr + A[:, 2] * (0.5 * L), r)]
+    return [(ctr, ctr.copy(), r)]
+
+
+def use_primitive_collision(m, max_radius=0.2, max_divisions=3, min_points=4):
+    """Replace every convex hull by its fitted capsules / spheres; the contact generator then sees the
+    capsule END SPHERES as points with a radius (a capsule lying flat touches with both ends)."""
+    m = dict(m)
+    xyz, rad, start = [], [], [0]
+    gs = m["hull_group_start"]
+    for b in range(m["nb"]):
+        for g in range(len(gs) - 1):
+            if not (m["hull_start"][b] <= gs[g] < m["hull_start"][b + 1]):
+                continue
+            for p0, p1, r in fit_primitives(m["hull_xyz"][gs[g]:gs[g + 1]], max_radius, max_divisions, min_points):
+                xyz.append(p0); rad.append(r)
+                if np.abs(p1 - p0).max() > 0:
+                    xyz.append(p1); rad.append(r)
+        start.append(len(xyz))
+    m["hull_xyz"] = np.array(xyz).reshape(-1, 3)
+    m["hull_radius"] = np.array(rad)
+    m["hull_start"] = np.array(start, np.int32)
+    m["hull_group_start"] = np.array([0, len(xyz)], np.int32)
+    sc, sr = np.zeros((m["nb"], 3)), np.zeros(m["nb"])
+    for b in range(m["nb"]):
+        v, r = m["hull_xyz"][start[b]:start[b + 1]], m["hull_radius"][start[b]:start[b + 1]]
+        if len(v):
+            lo, hi = (v - r[:, None]).min(0), (v + r[:, None]).max(0)
+            sc[b] = 0.5 * (lo + hi)
+            sr[b] = (np.sqrt(((v - sc[b]) ** 2).sum(1)) + r).max()
+    m["sphere_center"], m["sphere_radius"] = sc, sr
     return m
 
 

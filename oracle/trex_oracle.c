@@ -59,6 +59,7 @@ typedef struct {
   real head_point[3];
   int nv;
   real *hull; /* [nv][3] body frame */
+  real *hull_r; /* [nv] support radius: 0 for hull vertices, > 0 for fitted sphere / capsule ends */
   int hull_start[NBMAX + 1];
   real sphere_c[NBMAX][3], sphere_r[NBMAX];
   real q_start[NBMAX], base_pos0[3], base_quat0[4];
@@ -319,7 +320,7 @@ static int generate_contacts(const Model *m, const State *s, const Work *k, Cont
     const real *Rz = k->R[b] + 6;
     real z0 = s->pos[2] + k->r[b][2] - fz;
     for (int v = m->hull_start[b]; v < m->hull_start[b + 1]; v++)
-      if (z0 + dot3(Rz, m->hull + 3 * v) < margin) { active[b] = 1; break; }
+      if (z0 + dot3(Rz, m->hull + 3 * v) - m->hull_r[v] < margin) { active[b] = 1; break; }
     n_active += active[b];
   }
   if (!n_active) return 0;
@@ -338,7 +339,7 @@ static int generate_contacts(const Model *m, const State *s, const Work *k, Cont
     for (int v = v0; v < v1; v++) {
       real w[3];
       matvec3(k->R[b], m->hull + 3 * v, w);
-      real d = s->pos[2] + k->r[b][2] + w[2] - fz;
+      real d = s->pos[2] + k->r[b][2] + w[2] - m->hull_r[v] - fz;
       if (d < margin) { ncand++; if (best < 0 || d < bd) { best = v; bd = d; } }
     }
     (void)ncand;
@@ -347,7 +348,8 @@ static int generate_contacts(const Model *m, const State *s, const Work *k, Cont
       for (int v = v0; v < v1; v++) {
         real w[3];
         matvec3(k->R[b], m->hull + 3 * v, w);
-        real x[3] = {k->r[b][0] + w[0], k->r[b][1] + w[1], k->r[b][2] + w[2]};
+        /* contact point = lowest point of the sphere around the (transformed) vertex */
+        real x[3] = {k->r[b][0] + w[0], k->r[b][1] + w[1], k->r[b][2] + w[2] - m->hull_r[v]};
         real d = s->pos[2] + x[2] - fz;
         if (!(d < margin)) continue;
         int dup = 0;
@@ -591,7 +593,7 @@ API Model *oracle_model_create(int nb, const int *parent, const double *axis, co
                                const double *jrot, const double *q_lower, const double *q_upper,
                                const double *jdamp, const double *mass, const double *com,
                                const double *inertia, const int *obs_order, int head_body,
-                               const double *head_point, int nv, const double *hull,
+                               const double *head_point, int nv, const double *hull, const double *hull_radius,
                                const int *hull_start, const double *sphere_c, const double *sphere_r,
                                const double *q_start, const double *base_pos0, const double *base_quat0,
                                const double *params) {
@@ -618,10 +620,12 @@ API Model *oracle_model_create(int nb, const int *parent, const double *axis, co
   m->nv = nv;
   m->hull = (real *)malloc(sizeof(real) * 3 * (nv ? nv : 1));
   for (int i = 0; i < 3 * nv; i++) m->hull[i] = (real)hull[i];
+  m->hull_r = (real *)calloc(nv ? nv : 1, sizeof(real));
+  if (hull_radius) for (int i = 0; i < nv; i++) m->hull_r[i] = (real)hull_radius[i];
   for (int i = 0; i < P_COUNT; i++) m->prm[i] = (real)params[i];
   return m;
 }
-API void oracle_model_destroy(Model *m) { if (m) { free(m->hull); free(m); } }
+API void oracle_model_destroy(Model *m) { if (m) { free(m->hull); free(m->hull_r); free(m); } }
 API void oracle_model_set_param(Model *m, int idx, double v) { m->prm[idx] = (real)v; }
 
 API State *oracle_state_create(const Model *m) {

@@ -109,3 +109,45 @@ def test_batch_create_without_gpu_fails_loudly(capi):
     with pytest.raises(capi.TrexError) as e:
         capi.Batch(m, 4)
     assert e.value.code == -5 and "no CPU fallback" in str(e.value)
+
+
+def test_primitive_fitting_known_answers_and_oracle_agreement(capi, model):
+    """SURVEY 8f-2. (a) the reference's own known answers (tools/mesh_primitives_test.py:9-23): a 10^3 grid
+    splits into 8 octants and, at max_radius 1.0 with the reference's 100-point octant threshold, into 8
+    geometries. (b) the C++ fitter (product) and the numpy fitter (oracle) produce the same end spheres."""
+    from oracle import trex_model as tm
+    sp = np.linspace(-1.0, 1.0, 10)
+    x, y, z = np.meshgrid(sp, sp, sp)
+    grid = np.stack([x.ravel(), y.ravel(), z.ravel()], 1)
+    assert len(tm.fit_primitives(grid, 1.0, 4, 100)) == 8
+    assert len(tm.fit_primitives(grid, 1e9, 4, 100)) == 1
+    om = tm.use_primitive_collision(model, 0.2, 3, 4)
+    m = capi.Model(ASSET_URDF)
+    np.testing.assert_array_equal(m.array("hull_group_start"), model["hull_group_start"])
+    assert len(m.array("hull_group_start")) == 29          # 28 convex hulls
+    m.use_primitive_collision(0.2, 3, 4)
+    np.testing.assert_array_equal(m.array("hull_start"), om["hull_start"])
+    np.testing.assert_allclose(m.array("hull_xyz").reshape(-1, 3), om["hull_xyz"], atol=1e-9)
+    np.testing.assert_allclose(m.array("hull_radius"), om["hull_radius"], atol=1e-9)
+    np.testing.assert_allclose(m.array("sphere_radius"), om["sphere_radius"], atol=1e-9)
+    assert len(om["hull_xyz"]) == 148 and om["hull_radius"].min() > 0.005
+    # the capsules follow their hull: no hull vertex is farther than 12 cm from the primitive surface (the
+    # reference's rule - radius from the minor box extents, length = major - 2 r - rounds corners off)
+    for b in range(model["nb"]):
+        v = model["hull_xyz"][model["hull_start"][b]:model["hull_start"][b + 1]]
+        gs = model["hull_group_start"]
+        for g in range(len(gs) - 1):
+            if not (model["hull_start"][b] <= gs[g] < model["hull_start"][b + 1]):
+                continue
+            pts = model["hull_xyz"][gs[g]:gs[g + 1]]
+            prims = tm.fit_primitives(pts, 0.2, 3, 4)
+            def dist(p):
+                best = 1e9
+                for p0, p1, r in prims:
+                    d = p1 - p0
+                    t = 0.0 if d @ d == 0 else np.clip((p - p0) @ d / (d @ d), 0, 1)
+                    best = min(best, np.linalg.norm(p - (p0 + t * d)) - r)
+                return best
+            assert max(dist(p) for p in pts) < 0.12
+    with pytest.raises(capi.TrexError):
+        m.use_primitive_collision(-1.0)

@@ -179,3 +179,55 @@ def test_launch_info_and_event_timing(capi=None):
     assert 0 < info["lds_bytes"] <= 20 * 1024          # 8 workgroups per CU must fit the 160 KB of LDS
     ms = v.batch.time_steps(torch.zeros(1000, 25, device=DEV), v.obs, v.rew, v.done, 5)
     assert 0.05 < ms < 50
+
+
+def test_primitive_collision_mode_matches_oracle(model):
+    """capsule / sphere collision primitives through the same kernel; oracle with the numpy
+    fit. One env-step from states along a landing, plus rest statistics (weight carried, contact count)."""
+    from oracle import oracle as O, trex_model as tm
+    from trex_gym.vec_env import TrexVecEnv
+    om = tm.use_primitive_collision(model, 0.2, 3, 4)
+    orc = O.Oracle(om)
+    q0 = model["q_start"][model["obs_order"]]
+    lo, hi = model["q_lower"][model["obs_order"]], model["q_upper"][model["obs_order"]]
+    rng = np.random.default_rng(9)
+    s = orc.new_state()
+    orc.reset(s)
+    states, acts = [], []
+    for t in range(240):
+        orc.step(s, np.clip(q0 + 0.1 * rng.normal(size=25), lo, hi))
+        if t % 8 == 0:
+            states.append(orc.get_state(s).astype(np.float32))
+            acts.append(np.clip(q0 + 0.1 * rng.normal(size=25), lo, hi).astype(np.float32))
+    states, acts = np.array(states), np.array(acts)
+    v = TrexVecEnv(len(states), urdf_path=ASSET_URDF, device=DEV, collision="primitives")
+    assert v.model.array("hull_radius").size == 148
+    v.reset()
+    v.set_state(torch.tensor(states))
+    obs, rew, _, _ = v.step(acts)
+    cnt = torch.zeros(len(states), dtype=torch.int32, device=DEV)
+    v.batch.contact_stats(cnt, None)
+    touched = 0
+    for k in range(len(states)):
+        s2 = orc.new_state()
+        orc.set_state(s2, states[k].astype(np.float64))
+        o, r, _ = orc.step(s2, acts[k].astype(np.float64))
+        np.testing.assert_allclose(obs[k, :25], o[:25], atol=1e-4)
+        np.testing.assert_allclose(obs[k, 25:50], o[25:50], atol=5e-3 * max(1.0, np.abs(o[25:50]).max()))
+        np.testing.assert_allclose(obs[k, 50:], o[50:], atol=5e-3 * np.abs(o[50:]).max() + 1.0)
+        assert abs(rew[k] - r) <= 2e-3 * abs(r) + 1e-3
+        nco = len(orc.contacts(s2)[0])
+        assert cnt[k].item() == nco
+        touched += nco > 0
+    assert touched > 10
+    # holding the start pose it lands and the primitives carry the weight, on the GPU too
+    vr = TrexVecEnv(2, urdf_path=ASSET_URDF, device=DEV, collision="primitives")
+    vr.reset()
+    a = np.tile(q0.astype(np.float32), (2, 1))
+    for t in range(400):
+        vr.step(a)
+    imp = torch.zeros(2, device=DEV)
+    vr.batch.contact_stats(None, imp)
+    w = model["mass"].sum() * 9.81
+    st = vr.get_state().cpu().numpy()[0]
+    assert abs(imp[0].item() / 0.002 - w) < 0.05 * w and 0.5 < st[2] < 3.0 and np.abs(st[7:13]).max() < 0.2

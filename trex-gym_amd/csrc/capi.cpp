@@ -192,6 +192,13 @@ int trex_model_set_start_pose(TrexModel *m, const double xyz[3], const double rp
   return TREX_OK;
 }
 
+int trex_model_use_primitive_collision(TrexModel *m, double max_radius, int max_divisions, int min_points) {
+  if (!m) return fail(TREX_E_INVALID, "null model");
+  if (!(max_radius > 0) || max_divisions < 0 || min_points < 1) return fail(TREX_E_INVALID, "bad primitive-fitting arguments");
+  trex::use_primitive_collision(m->host, max_radius, max_divisions, min_points);
+  return TREX_OK;
+}
+
 int trex_model_set_param(TrexModel *m, const char *name, double value) {
   if (!m || !name) return fail(TREX_E_INVALID, "null argument");
   double *p = m->host.prm.find(name);
@@ -233,6 +240,8 @@ int trex_model_get_array(const TrexModel *m, const char *name, double *out, int 
   else if (n == "head_point") v = {h.head_point.x, h.head_point.y, h.head_point.z};
   else if (n == "hull_xyz") push3(h.hull_xyz);
   else if (n == "hull_start") v.assign(h.hull_start.begin(), h.hull_start.end());
+  else if (n == "hull_radius") v = h.hull_radius;
+  else if (n == "hull_group_start") v.assign(h.hull_group_start.begin(), h.hull_group_start.end());
   else if (n == "sphere_center") push3(h.sphere_center);
   else if (n == "sphere_radius") v = h.sphere_radius;
   else if (n == "q_start") v = h.q_start;
@@ -289,7 +298,7 @@ int trex_batch_create(const TrexModel *model, int num_envs, int device, TrexBatc
   A(nl * 12 * sizeof(float), (void **)&link_tf_dev);
   if (r != hipSuccess) { cleanup(); return hip_fail(r, "hipMalloc"); }
   std::vector<float4> hull(nv ? nv : 1);
-  for (size_t i = 0; i < nv; i++) hull[i] = make_float4((float)model->host.hull_xyz[i].x, (float)model->host.hull_xyz[i].y, (float)model->host.hull_xyz[i].z, 0.f);
+  for (size_t i = 0; i < nv; i++) hull[i] = make_float4((float)model->host.hull_xyz[i].x, (float)model->host.hull_xyz[i].y, (float)model->host.hull_xyz[i].z, (float)model->host.hull_radius[i]);
   std::vector<float> ltf(nl * 12);
   for (size_t l = 0; l < nl; l++) {
     for (int k = 0; k < 9; k++) ltf[12 * l + k] = (float)model->host.link_tf[l].R.m[k];

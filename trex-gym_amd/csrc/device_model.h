@@ -41,7 +41,7 @@ struct TrexBatchArrays {
   uint8_t *motors_on;
   int32_t *contact_count;
   float *normal_impulse;
-  float4 *hull;  /* [nv] body-frame vertices, w unused */
+  float4 *hull;  /* [nv] body-frame collision points: xyz + support radius (0 for hull vertices) */
   int num_links;
   const int *link_body;   /* [L] body of each URDF link */
   const float *link_tf;   /* [L][12] body<-link transform: rotation row-major (9) + translation (3) */

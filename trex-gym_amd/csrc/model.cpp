@@ -288,7 +288,7 @@ HostModel load_model(const std::string &urdf_path, const char *collisions_dir, i
     if (root_name.empty()) throw LoadError(TREX_E_PARSE, "no root link (cycle)");
 
     // hull vertices per link, in link frame
-    std::map<std::string, std::vector<Vec3>> hulls;
+    std::map<std::string, std::vector<std::vector<Vec3>>> hull_groups;   // link -> one vertex list per hull
     bool have_collision = false;
     for (auto &l : links) have_collision |= !l.collisions.empty();
     std::string base_dir = dirname_of(urdf_path);
@@ -296,7 +296,8 @@ HostModel load_model(const std::string &urdf_path, const char *collisions_dir, i
       for (auto &l : links)
         for (auto &c : l.collisions) {
           auto v = read_obj_vertices(base_dir + "/" + c.file);
-          for (auto &p : v) hulls[l.name].push_back(apply(c.origin, p));
+          for (auto &p : v) p = apply(c.origin, p);
+          hull_groups[l.name].push_back(v);
         }
     } else if (collisions_dir) {
       std::map<std::string, std::pair<std::string, Tf>> vis;
@@ -318,7 +319,8 @@ HostModel load_model(const std::string &urdf_path, const char *collisions_dir, i
         auto v = read_dae_vertices(std::string(collisions_dir) + "/" + f);
         // COL_ilium_L is point-reflected relative to ilium_left.obj (scripts/make_assets.py)
         double sgn = (f == "COL_ilium_L_convex_hull.dae") ? -1.0 : 1.0;
-        for (auto &p : v) hulls[it->second.first].push_back(apply(it->second.second, sgn * p));
+        for (auto &p : v) p = apply(it->second.second, sgn * p);
+        hull_groups[it->second.first].push_back(v);
       }
     }
 
@@ -399,10 +401,14 @@ HostModel load_model(const std::string &urdf_path, const char *collisions_dir, i
       m.mass[i] = mass; m.com[i] = com;
       m.inertia[i] = {I[0], I[1], I[2], I[4], I[5], I[8]};
       size_t before = m.hull_xyz.size();
+      if (m.hull_group_start.empty()) m.hull_group_start.push_back(0);
       for (auto &[li, tf] : b.members) {
-        auto it = hulls.find(links[li].name);
-        if (it == hulls.end()) continue;
-        for (auto &p : it->second) m.hull_xyz.push_back(apply(tf, p));
+        auto it = hull_groups.find(links[li].name);
+        if (it == hull_groups.end()) continue;
+        for (auto &group : it->second) {
+          for (auto &p : group) m.hull_xyz.push_back(apply(tf, p));
+          m.hull_group_start.push_back((int)m.hull_xyz.size());
+        }
       }
       if (m.hull_xyz.size() > before) {
         Vec3 lo = m.hull_xyz[before], hi = lo;
@@ -419,6 +425,8 @@ HostModel load_model(const std::string &urdf_path, const char *collisions_dir, i
       }
       m.hull_start.push_back((int)m.hull_xyz.size());
     }
+    if (m.hull_group_start.empty()) m.hull_group_start.push_back(0);
+    m.hull_radius.assign(m.hull_xyz.size(), 0.0);
     if (m.head_body < 0) { m.head_body = 0; m.head_point = m.com[0]; }  // generic URDF: reward point = base COM
     m.link_names.resize(links.size()); m.link_body.assign(links.size(), 0); m.link_tf.resize(links.size());
     for (size_t l = 0; l < links.size(); l++) m.link_names[l] = links[l].name;
@@ -454,6 +462,140 @@ HostModel load_model(const std::string &urdf_path, const char *collisions_dir, i
   } catch (const std::exception &e) {
     *code = TREX_E_PARSE;
     throw std::runtime_error(std::string("model load failed: ") + e.what());
+  }
+}
+
+// ------------------------------------------------------------------ collision primitives
+namespace {
+
+// eigenvectors of a symmetric 3x3 (cyclic Jacobi), eigenvalues descending
+void eigen_sym3(const double a_in[9], double vec[9], double val[3]) {
+  double a[9], v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int i = 0; i < 9; i++) a[i] = a_in[i];
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = a[1] * a[1] + a[2] * a[2] + a[5] * a[5];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++) {
+        if (std::fabs(a[3 * p + q]) < 1e-300) continue;
+        double theta = (a[3 * q + q] - a[3 * p + p]) / (2 * a[3 * p + q]);
+        double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1));
+        double c = 1 / std::sqrt(t * t + 1), s = t * c;
+        for (int k = 0; k < 3; k++) {   // A <- A J
+          double akp = a[3 * k + p], akq = a[3 * k + q];
+          a[3 * k + p] = c * akp - s * akq; a[3 * k + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < 3; k++) {   // A <- J^T A
+          double apk = a[3 * p + k], aqk = a[3 * q + k];
+          a[3 * p + k] = c * apk - s * aqk; a[3 * q + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < 3; k++) {
+          double vkp = v[3 * k + p], vkq = v[3 * k + q];
+          v[3 * k + p] = c * vkp - s * vkq; v[3 * k + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  int idx[3] = {0, 1, 2};
+  std::sort(idx, idx + 3, [&](int i, int j) { return a[4 * i] > a[4 * j]; });
+  for (int c = 0; c < 3; c++) {
+    val[c] = a[4 * idx[c]];
+    for (int r = 0; r < 3; r++) vec[3 * r + c] = v[3 * r + idx[c]];
+  }
+}
+
+void fit_rec(const std::vector<Vec3> &pts, double max_radius, int max_div, int min_points, int depth, std::vector<Primitive> &out) {
+  Vec3 c;
+  for (auto &p : pts) c = c + p;
+  c = (1.0 / pts.size()) * c;
+  double mom[9] = {0};
+  for (auto &p : pts) {
+    double d[3] = {p.x - c.x, p.y - c.y, p.z - c.z};
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) mom[3 * i + j] += d[i] * d[j];
+  }
+  double vec[9], val[3];
+  eigen_sym3(mom, vec, val);
+  // z = dominant axis, y = second, x = y x z (tools/mesh_primitives.py:331-335); signs canonicalised
+  double z[3] = {vec[0], vec[3], vec[6]}, y[3] = {vec[1], vec[4], vec[7]};
+  for (double *a : {z, y}) {
+    int k = std::fabs(a[0]) >= std::fabs(a[1]) ? (std::fabs(a[0]) >= std::fabs(a[2]) ? 0 : 2) : (std::fabs(a[1]) >= std::fabs(a[2]) ? 1 : 2);
+    if (a[k] < 0) for (int i = 0; i < 3; i++) a[i] = -a[i];
+  }
+  double x[3] = {y[1] * z[2] - y[2] * z[1], y[2] * z[0] - y[0] * z[2], y[0] * z[1] - y[1] * z[0]};
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  std::vector<std::array<double, 3>> al(pts.size());
+  for (size_t i = 0; i < pts.size(); i++) {
+    double d[3] = {pts[i].x - c.x, pts[i].y - c.y, pts[i].z - c.z};
+    al[i] = {d[0] * x[0] + d[1] * x[1] + d[2] * x[2], d[0] * y[0] + d[1] * y[1] + d[2] * y[2], d[0] * z[0] + d[1] * z[1] + d[2] * z[2]};
+    for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], al[i][k]); hi[k] = std::max(hi[k], al[i][k]); }
+  }
+  double ctr_l[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
+  double hwl[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+  Vec3 ctr{c.x + x[0] * ctr_l[0] + y[0] * ctr_l[1] + z[0] * ctr_l[2], c.y + x[1] * ctr_l[0] + y[1] * ctr_l[1] + z[1] * ctr_l[2],
+           c.z + x[2] * ctr_l[0] + y[2] * ctr_l[1] + z[2] * ctr_l[2]};
+  double r = 0.5 * std::max(hwl[0], hwl[1]), L = hwl[2] - 2 * r;
+  if (r > max_radius && depth < max_div) {
+    static const int oct[8][3] = {{1, 1, 1}, {1, -1, 1}, {1, -1, -1}, {1, 1, -1}, {-1, 1, 1}, {-1, -1, 1}, {-1, -1, -1}, {-1, 1, -1}};
+    for (auto &o : oct) {
+      std::vector<Vec3> part;
+      for (size_t i = 0; i < pts.size(); i++) {
+        bool in = true;
+        for (int k = 0; k < 3; k++) in &= ((al[i][k] - ctr_l[k] >= 0) == (o[k] > 0));
+        if (in) part.push_back(pts[i]);
+      }
+      if ((int)part.size() > min_points) fit_rec(part, max_radius, max_div, min_points, depth + 1, out);
+    }
+    return;
+  }
+  if (L > 0) {
+    Vec3 h{0.5 * L * z[0], 0.5 * L * z[1], 0.5 * L * z[2]};
+    out.push_back({ctr - h, ctr + h, r});
+  } else {
+    out.push_back({ctr, ctr, r});
+  }
+}
+
+}  // namespace
+
+std::vector<Primitive> fit_primitives(const std::vector<Vec3> &points, double max_radius, int max_divisions, int min_points) {
+  std::vector<Primitive> out;
+  if (!points.empty()) fit_rec(points, max_radius, max_divisions, min_points, 0, out);
+  return out;
+}
+
+void use_primitive_collision(HostModel &m, double max_radius, int max_divisions, int min_points) {
+  std::vector<Vec3> xyz;
+  std::vector<double> rad;
+  std::vector<int> start{0};
+  for (int b = 0; b < m.nb; b++) {
+    for (size_t g = 0; g + 1 < m.hull_group_start.size(); g++) {
+      int g0 = m.hull_group_start[g], g1 = m.hull_group_start[g + 1];
+      if (!(m.hull_start[b] <= g0 && g0 < m.hull_start[b + 1])) continue;
+      std::vector<Vec3> pts(m.hull_xyz.begin() + g0, m.hull_xyz.begin() + g1);
+      for (auto &p : fit_primitives(pts, max_radius, max_divisions, min_points)) {
+        xyz.push_back(p.p0); rad.push_back(p.radius);
+        Vec3 d = p.p1 - p.p0;
+        if (std::max({std::fabs(d.x), std::fabs(d.y), std::fabs(d.z)}) > 0) { xyz.push_back(p.p1); rad.push_back(p.radius); }
+      }
+    }
+    start.push_back((int)xyz.size());
+  }
+  m.hull_xyz = xyz; m.hull_radius = rad; m.hull_start = start;
+  m.hull_group_start = {0, (int)xyz.size()};
+  for (int b = 0; b < m.nb; b++) {
+    m.sphere_center[b] = Vec3{}; m.sphere_radius[b] = 0; m.box_half[b] = Vec3{};
+    if (start[b + 1] == start[b]) continue;
+    Vec3 lo{1e300, 1e300, 1e300}, hi{-1e300, -1e300, -1e300};
+    for (int v = start[b]; v < start[b + 1]; v++) {
+      const Vec3 &p = xyz[v];
+      double r = rad[v];
+      lo = {std::min(lo.x, p.x - r), std::min(lo.y, p.y - r), std::min(lo.z, p.z - r)};
+      hi = {std::max(hi.x, p.x + r), std::max(hi.y, p.y + r), std::max(hi.z, p.z + r)};
+    }
+    Vec3 c = 0.5 * (lo + hi);
+    double rr = 0;
+    for (int v = start[b]; v < start[b + 1]; v++) rr = std::max(rr, std::sqrt(dot(xyz[v] - c, xyz[v] - c)) + rad[v]);
+    m.sphere_center[b] = c; m.sphere_radius[b] = rr; m.box_half[b] = 0.5 * (hi - lo);
   }
 }
 

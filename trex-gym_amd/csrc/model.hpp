@@ -55,7 +55,9 @@ struct HostModel {
   std::vector<int> link_body;
   std::vector<Tf> link_tf;
   std::vector<Vec3> hull_xyz;
+  std::vector<double> hull_radius;     // support radius per point: 0 for hull vertices, > 0 for fitted spheres
   std::vector<int> hull_start;
+  std::vector<int> hull_group_start;   // one group per original convex hull (CSR over hull_xyz)
   double total_mass = 0, total_mass_excluding_base = 0;
   Vec3 base_start_pos{0, 0, 3};           // trex_env.py:105
   double base_start_quat[4] = {0, 0, 0, 1};  // trex_env.py:106 rpy = 0
@@ -66,6 +68,13 @@ struct HostModel {
 HostModel load_model(const std::string &urdf_path, const char *collisions_dir, int *code);
 
 std::string rename_v0_name(const std::string &name);  // femur_L_joint -> joint_femur_left
+
+// Collision primitives: the capsule / sphere fitting of the reference's
+// tools/mesh_primitives.py:323-402, restated. Returns capsules as (p0, p1, radius); p0 == p1 = sphere.
+struct Primitive { Vec3 p0, p1; double radius; };
+std::vector<Primitive> fit_primitives(const std::vector<Vec3> &points, double max_radius, int max_divisions, int min_points);
+// Replace every hull of the model by the end spheres of its fitted primitives.
+void use_primitive_collision(HostModel &m, double max_radius, int max_divisions, int min_points);
 Mat3 rpy_to_matrix(double r, double p, double y);
 void matrix_to_quat(const Mat3 &m, double q[4]);
 

@@ -829,9 +829,10 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
             const float hv[3] = {h[u].x, h[u].y, h[u].z};
             float w[3];
             matvec3(R, hv, w);
-            const float dd = pos[2] + r[2] + w[2] - floor_z;
+            // h.w = support radius (0 for a hull vertex): the contact point is the sphere's lowest point
+            const float dd = pos[2] + r[2] + w[2] - h[u].w - floor_z;
             if (small && i < nverts && dd < margin && -dd > bs) {
-              bs = -dd; a_v = hull_v0 + i; a_x[0] = r[0] + w[0]; a_x[1] = r[1] + w[1]; a_x[2] = r[2] + w[2]; a_d = dd;
+              bs = -dd; a_v = hull_v0 + i; a_x[0] = r[0] + w[0]; a_x[1] = r[1] + w[1]; a_x[2] = r[2] + w[2] - h[u].w; a_d = dd;
             }
           }
         }
@@ -857,8 +858,8 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
           const float hv[3] = {h.x, h.y, h.z};
           float w[3];
           matvec3(Rb, hv, w);
-          const float dd = pos[2] + rb[2] + w[2] - floor_z;
-          if (dd < margin && -dd > bs) { bs = -dd; bi = v; bx[0] = rb[0] + w[0]; bx[1] = rb[1] + w[1]; bx[2] = rb[2] + w[2]; }
+          const float dd = pos[2] + rb[2] + w[2] - h.w - floor_z;
+          if (dd < margin && -dd > bs) { bs = -dd; bi = v; bx[0] = rb[0] + w[0]; bx[1] = rb[1] + w[1]; bx[2] = rb[2] + w[2] - h.w; }
         }
         const int mine = bi;
         targmax(bs, bi);
@@ -922,7 +923,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
               const float hv[3] = {h.x, h.y, h.z};
               float w[3];
               matvec3(Rb, hv, w);
-              const float x0 = rb[0] + w[0], x1 = rb[1] + w[1], x2 = rb[2] + w[2];
+              const float x0 = rb[0] + w[0], x1 = rb[1] + w[1], x2 = rb[2] + w[2] - h.w;
               const float dd = pos[2] + x2 - floor_z;
               if (!(dd < margin)) continue;
               if (v == sel[0] || v == sel[1] || v == sel[2]) continue;

@@ -35,6 +35,7 @@ SYMBOLS = [
     "trex_batch_set_motors_enabled", "trex_batch_head_position", "trex_batch_set_domain",
     "trex_batch_contact_stats", "trex_batch_debug_step", "trex_batch_launch_info", "trex_batch_time_steps",
     "trex_model_num_links", "trex_model_link_info", "trex_batch_link_transforms",
+    "trex_model_use_primitive_collision",
 ]
 
 _vp = C.c_void_p
@@ -67,6 +68,7 @@ lib.trex_batch_set_state.argtypes = [_vp, _vp, _vp]
 lib.trex_batch_set_motors_enabled.argtypes = [_vp, C.c_int, _vp]
 lib.trex_batch_head_position.argtypes = [_vp, _vp, _vp]
 lib.trex_batch_set_domain.argtypes = [_vp, _vp, _vp, _vp]
+lib.trex_model_use_primitive_collision.argtypes = [_vp, C.c_double, C.c_int, C.c_int]
 lib.trex_model_num_links.argtypes = [_vp]
 lib.trex_model_link_info.argtypes = [_vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
 lib.trex_batch_link_transforms.argtypes = [_vp, _vp, _vp]
@@ -137,6 +139,10 @@ class Model:
             check(lib.trex_model_link_info(self.h, k, C.byref(name), C.byref(body)))
             out.append((name.value.decode(), body.value))
         return out
+
+    def use_primitive_collision(self, max_radius=0.2, max_divisions=3, min_points=4):
+        """Replace the convex hulls by fitted capsules / spheres (tools/mesh_primitives.py:323-402)."""
+        check(lib.trex_model_use_primitive_collision(self.h, float(max_radius), int(max_divisions), int(min_points)))
 
     def total_mass(self, include_base_link=False):
         return lib.trex_model_total_mass(self.h, int(include_base_link))

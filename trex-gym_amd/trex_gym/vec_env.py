@@ -25,7 +25,7 @@ class TrexVecEnv:
     def __init__(self, num_envs, urdf_path=None, collisions_dir=None, device=None, action_repeat=1,
                  distance_weight=1.0, energy_weight=0.005, drift_weight=0.002,
                  max_episode_steps=None, starting_configuration=None, params=None,
-                 rank=0, world_size=1, process_group=None):
+                 rank=0, world_size=1, process_group=None, collision="hulls", primitive_max_radius=0.2):
         """num_envs is the GLOBAL env count; this process owns sharding.shard_range(num_envs, rank, world_size)."""
         self.global_num_envs = int(num_envs)
         self.rank, self.world_size, self.process_group = int(rank), int(world_size), process_group
@@ -41,6 +41,10 @@ class TrexVecEnv:
         self.model.set_param("substeps", 5 * int(action_repeat))
         for k, v in (params or {}).items():
             self.model.set_param(k, v)
+        if collision == "primitives":   # capsules / spheres fitted to the hulls
+            self.model.use_primitive_collision(primitive_max_radius)
+        elif collision != "hulls":
+            raise ValueError("collision must be 'hulls' or 'primitives'")
         for name, angle in (starting_configuration or {}).items():
             self.model.set_start_angle(name, angle)  # unknown name raises, like KeyError at trex_robot.py:307
         self.batch = _capi.Batch(self.model, self.num_envs, self.device.index or 0)
