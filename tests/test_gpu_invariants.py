@@ -1,5 +1,7 @@
 """Physics invariants checked ON THE GPU PATH itself (not only on the oracle), and a second, tiny
 model through the same kernel: the HIP code is not specialised to the T-rex tree."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -231,3 +233,17 @@ def test_primitive_collision_mode_matches_oracle(model):
     w = model["mass"].sum() * 9.81
     st = vr.get_state().cpu().numpy()[0]
     assert abs(imp[0].item() / 0.002 - w) < 0.05 * w and 0.5 < st[2] < 3.0 and np.abs(st[7:13]).max() < 0.2
+
+
+def test_cpp_caller_of_the_c_abi():
+    """trex_capi_example: a C++ program on the C-ABI with hipMalloc buffers (no Python, no torch)."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "trex-gym_amd", "trex_gym", "trex_capi_example")
+    if not os.path.exists(exe):
+        pytest.skip("example binary not built (make -C trex-gym_amd/csrc example)")
+    r = subprocess.run([exe, ASSET_URDF, "1024", "50"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "26 bodies, 25 joints (132 URDF joints), 2181 hull vertices" in r.stdout
+    rate = float(r.stdout.strip().splitlines()[-1].split("=")[-1].split()[0])
+    assert rate > 1e5
