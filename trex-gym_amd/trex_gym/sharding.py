@@ -49,12 +49,13 @@ def all_gather_rows(local, global_rows, world_size, group=None, out=None):
     if local.shape[0] != per:
         send = torch.zeros((per,) + tuple(cols), dtype=local.dtype, device=local.device)
         send[: local.shape[0]] = local
-    buf = torch.empty((world_size * per,) + tuple(cols), dtype=local.dtype, device=local.device)
+    even = world_size * per == global_rows
+    if even and out is not None and tuple(out.shape) == (global_rows,) + tuple(cols):
+        buf = out   # gather straight into the caller's buffer: no allocation, no copy per step
+    else:
+        buf = torch.empty((world_size * per,) + tuple(cols), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(buf, send.contiguous(), group=group)
-    if world_size * per == global_rows:
-        if out is not None:
-            out.copy_(buf)
-            return out
+    if even:
         return buf
     pieces = []
     for r in range(world_size):
