@@ -71,6 +71,11 @@ int trex_model_set_start_pose(TrexModel *model, const double xyz[3], const doubl
  * subdivision while radius > max_radius). Contacts are then generated from the capsule end spheres
  * (148 points instead of 2 181 vertices for trex.urdf at max_radius 0.2). Call before trex_batch_create. */
 int trex_model_use_primitive_collision(TrexModel *model, double max_radius, int max_divisions, int min_points);
+/* The fit of ONE convex hull (group g of "hull_group_start", body-frame coordinates) without changing the
+ * model: writes up to `capacity` primitives as 7 doubles each (p0 xyz, p1 xyz, radius; p0 == p1 = sphere)
+ * and returns their number (MJCF export, tests). */
+int trex_model_fit_hull_primitives(const TrexModel *model, int group, double max_radius, int max_divisions,
+                                   int min_points, double *out, int capacity);
 
 /* engine parameters: "dt" "substeps" "iterations" "gravity" "motor_kp" "motor_kd" "motor_max_force"
  * "floor_z" "friction" "erp" "contact_erp" "contact_margin" "link_damping"

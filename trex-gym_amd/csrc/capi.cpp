@@ -199,6 +199,25 @@ int trex_model_use_primitive_collision(TrexModel *m, double max_radius, int max_
   return TREX_OK;
 }
 
+int trex_model_fit_hull_primitives(const TrexModel *m, int group, double max_radius, int max_divisions, int min_points,
+                                   double *out, int capacity) {
+  if (!m) return fail(TREX_E_INVALID, "null model");
+  const auto &gs = m->host.hull_group_start;
+  if (group < 0 || group + 1 >= (int)gs.size()) return fail(TREX_E_INVALID, "hull group out of range");
+  if (!(max_radius > 0) || max_divisions < 0 || min_points < 1) return fail(TREX_E_INVALID, "bad primitive-fitting arguments");
+  std::vector<trex::Vec3> pts(m->host.hull_xyz.begin() + gs[group], m->host.hull_xyz.begin() + gs[group + 1]);
+  auto prims = trex::fit_primitives(pts, max_radius, max_divisions, min_points);
+  if (out) {
+    if (capacity < (int)prims.size()) return fail(TREX_E_INVALID, "capacity too small");
+    for (size_t i = 0; i < prims.size(); i++) {
+      double *o = out + 7 * i;
+      o[0] = prims[i].p0.x; o[1] = prims[i].p0.y; o[2] = prims[i].p0.z;
+      o[3] = prims[i].p1.x; o[4] = prims[i].p1.y; o[5] = prims[i].p1.z; o[6] = prims[i].radius;
+    }
+  }
+  return (int)prims.size();
+}
+
 int trex_model_set_param(TrexModel *m, const char *name, double value) {
   if (!m || !name) return fail(TREX_E_INVALID, "null argument");
   double *p = m->host.prm.find(name);

@@ -35,7 +35,7 @@ SYMBOLS = [
     "trex_batch_set_motors_enabled", "trex_batch_head_position", "trex_batch_set_domain",
     "trex_batch_contact_stats", "trex_batch_debug_step", "trex_batch_launch_info", "trex_batch_time_steps",
     "trex_model_num_links", "trex_model_link_info", "trex_batch_link_transforms",
-    "trex_model_use_primitive_collision",
+    "trex_model_use_primitive_collision", "trex_model_fit_hull_primitives",
 ]
 
 _vp = C.c_void_p
@@ -69,6 +69,7 @@ lib.trex_batch_set_motors_enabled.argtypes = [_vp, C.c_int, _vp]
 lib.trex_batch_head_position.argtypes = [_vp, _vp, _vp]
 lib.trex_batch_set_domain.argtypes = [_vp, _vp, _vp, _vp]
 lib.trex_model_use_primitive_collision.argtypes = [_vp, C.c_double, C.c_int, C.c_int]
+lib.trex_model_fit_hull_primitives.argtypes = [_vp, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int]
 lib.trex_model_num_links.argtypes = [_vp]
 lib.trex_model_link_info.argtypes = [_vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
 lib.trex_batch_link_transforms.argtypes = [_vp, _vp, _vp]
@@ -143,6 +144,14 @@ class Model:
     def use_primitive_collision(self, max_radius=0.2, max_divisions=3, min_points=4):
         """Replace the convex hulls by fitted capsules / spheres (tools/mesh_primitives.py:323-402)."""
         check(lib.trex_model_use_primitive_collision(self.h, float(max_radius), int(max_divisions), int(min_points)))
+
+    def fit_hull_primitives(self, group, max_radius=0.2, max_divisions=3, min_points=4):
+        """[(p0, p1, radius)] fitted to convex hull `group` (body frame); p0 == p1 for a sphere."""
+        n = check(lib.trex_model_fit_hull_primitives(self.h, group, max_radius, max_divisions, min_points, None, 0))
+        out = np.zeros((n, 7))
+        check(lib.trex_model_fit_hull_primitives(self.h, group, max_radius, max_divisions, min_points,
+                                                 out.ctypes.data_as(C.POINTER(C.c_double)), n))
+        return [(o[0:3].copy(), o[3:6].copy(), float(o[6])) for o in out]
 
     def total_mass(self, include_base_link=False):
         return lib.trex_model_total_mass(self.h, int(include_base_link))
