@@ -24,6 +24,26 @@ def test_ppo_runs_on_device_and_the_critic_learns():
     assert torch.isfinite(agent.obs).all()
 
 
+def test_ppo_with_hip_graphs():
+    """Same trainer with the rollout (32 env steps + policy) and the minibatch update replayed as HIP graphs."""
+    from trex_gym import trex_train
+    env = trex_train.build_environment(4096, max_episode_steps=200)
+    logs = []
+    agent, hist = trex_train.train(env, num_timesteps=4096 * 32 * 8, seed=0, nsteps=32, noptepochs=4, log=logs.append,
+                                   use_graphs=True)
+    print("\n".join(logs))
+    assert len(hist) == 8
+    assert all(math.isfinite(h[k]) for h in hist for k in ("policy_loss", "value_loss", "entropy", "mean_step_reward"))
+    assert hist[-1]["value_loss"] < 0.1 * hist[0]["value_loss"]
+    assert hist[-1]["env_steps_per_s"] > 2e5
+    assert torch.isfinite(agent.obs).all()
+    # replay == eager: the first iteration (same seed, same Philox offsets) gives the same statistics
+    env2 = trex_train.build_environment(4096, max_episode_steps=200)
+    _, hist2 = trex_train.train(env2, num_timesteps=4096 * 32, seed=0, nsteps=32, noptepochs=4, log=lambda s: None)
+    for k in ("mean_step_reward", "value_loss", "entropy"):
+        assert abs(hist[0][k] - hist2[0][k]) <= 2e-3 * abs(hist2[0][k]), (k, hist[0][k], hist2[0][k])
+
+
 def test_running_mean_std_matches_batch_statistics():
     from trex_gym.ppo import RunningMeanStd
     g = torch.Generator(device="cuda:0").manual_seed(0)

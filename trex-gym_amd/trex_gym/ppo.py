@@ -24,17 +24,17 @@ class RunningMeanStd:
     def __init__(self, shape, device):
         self.mean = torch.zeros(shape, device=device, dtype=torch.float64)
         self.var = torch.ones(shape, device=device, dtype=torch.float64)
-        self.count = 1e-4
+        self.count = torch.full((), 1e-4, device=device, dtype=torch.float64)   # tensor: updates are graph-capturable
 
     def update(self, x):
         x = x.to(torch.float64).reshape(-1, *self.mean.shape)
         bm, bv, bc = x.mean(0), x.var(0, unbiased=False), x.shape[0]
         delta = bm - self.mean
         tot = self.count + bc
-        self.mean = self.mean + delta * bc / tot
         m2 = self.var * self.count + bv * bc + delta * delta * self.count * bc / tot
-        self.var = m2 / tot
-        self.count = tot
+        self.mean.copy_(self.mean + delta * bc / tot)   # in place: the tensors keep their addresses for graph replay
+        self.var.copy_(m2 / tot)
+        self.count.copy_(tot)
 
 
 class MlpPolicy(nn.Module):
@@ -53,7 +53,7 @@ class MlpPolicy(nn.Module):
         self.logstd = nn.Parameter(torch.zeros(act_dim))
 
     def dist(self, obs):
-        return torch.distributions.Normal(self.pi(obs), self.logstd.exp())
+        return torch.distributions.Normal(self.pi(obs), self.logstd.exp(), validate_args=False)   # the check syncs: not capturable
 
     def value(self, obs):
         return self.vf(obs).squeeze(-1)
@@ -62,7 +62,10 @@ class MlpPolicy(nn.Module):
 class PPO:
     def __init__(self, env, nsteps=32, nminibatches=32, noptepochs=4, gamma=0.99, lam=0.95, lr=3e-4,
                  cliprange=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, clip_obs=10.0, clip_rew=10.0,
-                 seed=0):
+                 seed=0, use_graphs=False):
+        """use_graphs: capture the whole nsteps rollout (policy + env step + normalisation) and one
+        minibatch update as HIP graphs and replay them - the env step launches nothing but stream-ordered
+        kernels, so it is capture-safe (tests/test_gpu_invariants.py)."""
         self.env = env
         self.dev = env.device
         self.nsteps, self.nminibatches, self.noptepochs = nsteps, nminibatches, noptepochs
@@ -72,12 +75,23 @@ class PPO:
         torch.manual_seed(seed)
         n, od, ad = env.num_envs, env.observation_space.shape[0], env.action_space.shape[0]
         self.policy = MlpPolicy(od, ad).to(self.dev)
-        self.opt = torch.optim.Adam(self.policy.parameters(), lr=lr, eps=1e-5)
+        self.use_graphs = use_graphs
+        self.opt = torch.optim.Adam(self.policy.parameters(), lr=lr, eps=1e-5, capturable=use_graphs)
+        self._rollout_graph = self._update_graph = None
         self.obs_rms = RunningMeanStd((od,), self.dev)
         self.ret_rms = RunningMeanStd((), self.dev)
         self.ret = torch.zeros(n, device=self.dev)
         self.obs = self._norm_obs(env.reset_tensor().clone(), update=True)
         self.total_env_steps = 0
+        T = nsteps
+        self.b_obs = torch.empty(T, n, od, device=self.dev)
+        self.b_act = torch.empty(T, n, ad, device=self.dev)
+        self.b_logp = torch.empty(T, n, device=self.dev)
+        self.b_val = torch.empty(T + 1, n, device=self.dev)
+        self.b_rew = torch.empty(T, n, device=self.dev)
+        self.b_done = torch.empty(T, n, device=self.dev)
+        self.b_adv = torch.empty(T, n, device=self.dev)
+        self.raw_rew = torch.zeros((), device=self.dev, dtype=torch.float64)
 
     # VecNormalize (trex_train.py:45)
     def _norm_obs(self, obs, update):
@@ -87,70 +101,110 @@ class PPO:
         return o.clamp(-self.clip_obs, self.clip_obs).to(torch.float32)
 
     def _norm_rew(self, rew, done):
-        self.ret = self.ret * self.gamma + rew
+        self.ret.mul_(self.gamma).add_(rew)     # in place: a captured rollout must carry the returns over replays
         self.ret_rms.update(self.ret)
         r = (rew.to(torch.float64) / torch.sqrt(self.ret_rms.var + 1e-8)).clamp(-self.clip_rew, self.clip_rew)
-        self.ret = torch.where(done, torch.zeros_like(self.ret), self.ret)
+        self.ret.masked_fill_(done, 0.0)
         return r.to(torch.float32)
+
+    @torch.no_grad()
+    def _rollout(self):
+        """nsteps env steps with the current policy + GAE, everything into the preallocated buffers."""
+        T = self.nsteps
+        self.raw_rew.zero_()
+        for t in range(T):
+            d = self.policy.dist(self.obs)
+            a = d.loc + d.scale * torch.randn_like(d.loc)   # torch.normal(mean, std) checks std on the host: not capturable
+            self.b_obs[t].copy_(self.obs); self.b_act[t].copy_(a)
+            self.b_logp[t].copy_(d.log_prob(a).sum(-1)); self.b_val[t].copy_(self.policy.value(self.obs))
+            obs, rew, done = self.env.step_tensor(a)   # the env clips to the joint limits (trex_env.py:147)
+            self.raw_rew += rew.double().mean()
+            self.b_rew[t].copy_(self._norm_rew(rew, done))
+            self.b_done[t].copy_(done.float())
+            self.obs.copy_(self._norm_obs(obs, update=True))
+        self.b_val[T].copy_(self.policy.value(self.obs))
+        last = torch.zeros_like(self.b_val[0])
+        for t in reversed(range(T)):
+            nonterm = 1.0 - self.b_done[t]
+            delta = self.b_rew[t] + self.gamma * self.b_val[t + 1] * nonterm - self.b_val[t]
+            last = delta + self.gamma * self.lam * nonterm * last
+            self.b_adv[t].copy_(last)
 
     @torch.no_grad()
     def collect(self):
         T, n = self.nsteps, self.env.num_envs
-        od, ad = self.obs.shape[1], self.env.action_space.shape[0]
-        b_obs = torch.empty(T, n, od, device=self.dev)
-        b_act = torch.empty(T, n, ad, device=self.dev)
-        b_logp = torch.empty(T, n, device=self.dev)
-        b_val = torch.empty(T + 1, n, device=self.dev)
-        b_rew = torch.empty(T, n, device=self.dev)
-        b_done = torch.empty(T, n, device=self.dev)
-        raw_rew = torch.zeros((), device=self.dev, dtype=torch.float64)
-        for t in range(T):
-            d = self.policy.dist(self.obs)
-            a = d.sample()
-            b_obs[t], b_act[t], b_logp[t], b_val[t] = self.obs, a, d.log_prob(a).sum(-1), self.policy.value(self.obs)
-            obs, rew, done = self.env.step_tensor(a)   # the env clips to the joint limits (trex_env.py:147)
-            raw_rew += rew.double().mean()
-            b_rew[t] = self._norm_rew(rew, done)
-            b_done[t] = done.float()
-            self.obs = self._norm_obs(obs, update=True)
-        b_val[T] = self.policy.value(self.obs)
-        adv = torch.empty(T, n, device=self.dev)
-        last = torch.zeros(n, device=self.dev)
-        for t in reversed(range(T)):
-            nonterm = 1.0 - b_done[t]
-            delta = b_rew[t] + self.gamma * b_val[t + 1] * nonterm - b_val[t]
-            last = delta + self.gamma * self.lam * nonterm * last
-            adv[t] = last
-        ret = adv + b_val[:T]
+        if self.use_graphs:
+            if self._rollout_graph is None:
+                torch.cuda.synchronize()
+                self._rollout_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._rollout_graph):
+                    self._rollout()
+            self._rollout_graph.replay()
+        else:
+            self._rollout()
         self.total_env_steps += T * n
         flat = lambda x: x.reshape(T * n, *x.shape[2:])
-        return flat(b_obs), flat(b_act), flat(b_logp), flat(b_val[:T]), flat(adv), flat(ret), (raw_rew / T).item()
+        ret = self.b_adv + self.b_val[:T]
+        return (flat(self.b_obs), flat(self.b_act), flat(self.b_logp), flat(self.b_val[:T]), flat(self.b_adv), flat(ret),
+                (self.raw_rew / T).item())
+
+    def _minibatch_step(self, obs, act, logp0, val0, adv, ret):
+        a = (adv - adv.mean()) / (adv.std() + 1e-8)
+        d = self.policy.dist(obs)
+        logp = d.log_prob(act).sum(-1)
+        ratio = (logp - logp0).exp()
+        pg = torch.max(-a * ratio, -a * ratio.clamp(1 - self.cliprange, 1 + self.cliprange)).mean()
+        v = self.policy.value(obs)
+        vclip = val0 + (v - val0).clamp(-self.cliprange, self.cliprange)
+        vf = 0.5 * torch.max((v - ret) ** 2, (vclip - ret) ** 2).mean()
+        ent = d.entropy().sum(-1).mean()
+        loss = pg - self.ent_coef * ent + self.vf_coef * vf
+        self.opt.zero_grad(set_to_none=False)
+        loss.backward()
+        nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
+        self.opt.step()
+        return pg.detach(), vf.detach(), ent.detach()
 
     def update(self, batch):
         obs, act, logp0, val0, adv, ret, _ = batch
         N = obs.shape[0]
         mb = N // self.nminibatches
+        if self.use_graphs and self._update_graph is None:
+            # static minibatch buffers + one captured optimiser step (warm-up on a side stream first)
+            self._mb = [torch.empty((mb,) + tuple(x.shape[1:]), device=self.dev) for x in (obs, act, logp0, val0, adv, ret)]
+            for x, src in zip(self._mb, (obs, act, logp0, val0, adv, ret)):
+                x.copy_(src[:mb])
+            keep = [p.detach().clone() for p in self.policy.parameters()]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    self._minibatch_step(*self._mb)
+            torch.cuda.current_stream().wait_stream(side)
+            with torch.no_grad():                 # undo the warm-up: same parameters and a fresh Adam state
+                for p, k in zip(self.policy.parameters(), keep):
+                    p.copy_(k)
+                for st in self.opt.state.values():
+                    for v in st.values():
+                        if torch.is_tensor(v):
+                            v.zero_()
+            torch.cuda.synchronize()
+            self._update_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._update_graph):
+                self._mb_out = self._minibatch_step(*self._mb)
         stats = []
         for _ in range(self.noptepochs):
             perm = torch.randperm(N, device=self.dev)
             for k in range(self.nminibatches):
                 idx = perm[k * mb:(k + 1) * mb]
-                a = adv[idx]
-                a = (a - a.mean()) / (a.std() + 1e-8)
-                d = self.policy.dist(obs[idx])
-                logp = d.log_prob(act[idx]).sum(-1)
-                ratio = (logp - logp0[idx]).exp()
-                pg = torch.max(-a * ratio, -a * ratio.clamp(1 - self.cliprange, 1 + self.cliprange)).mean()
-                v = self.policy.value(obs[idx])
-                vclip = val0[idx] + (v - val0[idx]).clamp(-self.cliprange, self.cliprange)
-                vf = 0.5 * torch.max((v - ret[idx]) ** 2, (vclip - ret[idx]) ** 2).mean()
-                ent = d.entropy().sum(-1).mean()
-                loss = pg - self.ent_coef * ent + self.vf_coef * vf
-                self.opt.zero_grad(set_to_none=True)
-                loss.backward()
-                nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
-                self.opt.step()
-            stats.append((pg.detach(), vf.detach(), ent.detach()))
+                if self.use_graphs:
+                    for x, src in zip(self._mb, (obs, act, logp0, val0, adv, ret)):
+                        torch.index_select(src, 0, idx, out=x)
+                    self._update_graph.replay()
+                    out = self._mb_out
+                else:
+                    out = self._minibatch_step(obs[idx], act[idx], logp0[idx], val0[idx], adv[idx], ret[idx])
+            stats.append(tuple(o.clone() for o in out))
         pg, vf, ent = (torch.stack(x).mean().item() for x in zip(*stats))
         return dict(policy_loss=pg, value_loss=vf, entropy=ent)
 

@@ -23,9 +23,9 @@ def build_environment(num_envs, device="cuda:0", max_episode_steps=1000):
                       drift_weight=1.0, max_episode_steps=max_episode_steps)
 
 
-def train(env, num_timesteps, seed, nsteps=32, noptepochs=4, save_path=None, log=print):
+def train(env, num_timesteps, seed, nsteps=32, noptepochs=4, save_path=None, log=print, use_graphs=False):
     agent = PPO(env, nsteps=nsteps, nminibatches=32, noptepochs=noptepochs, lam=0.95, gamma=0.99, lr=3e-4,
-                cliprange=0.2, ent_coef=0.0, seed=seed)
+                cliprange=0.2, ent_coef=0.0, seed=seed, use_graphs=use_graphs)
     log("Number of actions: %d; number of joints: %d; model mass: %.2f; nsteps %d x %d envs; noptepochs %d"
         % (env.action_space.shape[0], env.model.num_joints, env.model.total_mass(False), nsteps, env.num_envs, noptepochs))
     hist = agent.learn(num_timesteps, log=log)
@@ -44,9 +44,10 @@ def main(argv=None):
     ap.add_argument("--nsteps", type=int, default=32)
     ap.add_argument("--noptepochs", type=int, default=4)
     ap.add_argument("--save", type=str, default=None)
+    ap.add_argument("--graphs", action="store_true", help="replay the rollout and the minibatch update as HIP graphs")
     args = ap.parse_args(argv)
     env = build_environment(args.num_envs)
-    train(env, args.num_timesteps, args.random_seed, args.nsteps, args.noptepochs, args.save)
+    train(env, args.num_timesteps, args.random_seed, args.nsteps, args.noptepochs, args.save, use_graphs=args.graphs)
 
 
 if __name__ == "__main__":

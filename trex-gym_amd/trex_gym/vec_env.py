@@ -88,7 +88,7 @@ class TrexVecEnv:
             # VecEnv auto-reset without a host sync: the masked reset kernel is launched every step
             # (teams whose mask is 0 skip the physics) and obs becomes that of the new episode.
             self.episode_steps += 1
-            done = self.episode_steps >= self.max_episode_steps
+            done = done | (self.episode_steps >= self.max_episode_steps)   # time limit, or a contained non-finite env
             self.batch.reset(self.obs, done.to(torch.uint8))
             self.episode_steps.masked_fill_(done, 0)
         return self.obs, self.rew, done
