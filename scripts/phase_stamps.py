@@ -21,7 +21,7 @@ NAMES = ["FK + velocities", "inertia, bias", "ABA pass 2 (LDS)", "base 6x6 inver
 
 def main():
     dev = torch.device("cuda:0")
-    n = 4096
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096   # 512 = one wave per CU: a wave alone on its SIMD
     m = _capi.Model()
     b = _capi.Batch(m, n)
     obs = torch.zeros(n, 75, device=dev); rew = torch.zeros(n, device=dev); done = torch.zeros(n, dtype=torch.uint8, device=dev)
