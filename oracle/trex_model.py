@@ -443,5 +443,5 @@ def default_params():
         contact_margin=0.02,    # contactBreakingThreshold [EXT]
         link_damping=0.04,      # btMultiBody linear = angular damping [EXT]
         max_coordinate_velocity=100.0,  # btMultiBody m_maxCoordinateVelocity [EXT]
-        max_contacts=16,
+        max_contacts=13,   # 25 motor rows + 3 x 13 contact rows = the 64 lanes of a wavefront
     )

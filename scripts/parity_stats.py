@@ -16,8 +16,10 @@ from trex_gym.vec_env import TrexVecEnv  # noqa: E402
 
 
 def main():
+    # optional name=value parameter overrides (both sides), e.g. iterations=10 motor_max_force=3e9
+    prm = {a.split("=")[0]: float(a.split("=")[1]) for a in sys.argv[1:]}
     om = tm.compile_model(O.default_asset_urdf())
-    orc = O.Oracle(om)
+    orc = O.Oracle(om, params=prm)
     order = om["obs_order"]
     lo, hi, q0 = om["q_lower"][order], om["q_upper"][order], om["q_start"][order]
     rng = np.random.default_rng(11)
@@ -35,7 +37,7 @@ def main():
                             np.clip(q0 + 0.15 * rng.normal(size=25), lo, hi).astype(np.float32))
     states, acts = np.array(states), np.array(acts)
     n = len(states)
-    v = TrexVecEnv(n, device="cuda:0")
+    v = TrexVecEnv(n, device="cuda:0", params=prm)
     v.reset()
     v.set_state(torch.tensor(states))
     obs, rew, _, _ = v.step(acts)

@@ -15,8 +15,8 @@ sys.path.insert(0, os.path.join(ROOT, "trex-gym_amd"))
 from trex_gym import _capi, sharding  # noqa: E402
 
 NAMES = ["FK + velocities", "inertia, bias", "ABA pass 2 (LDS)", "base 6x6 inverse", "ABA pass 3 + vel update",
-         "factorisation A", "M^-1 joint columns", "joint rows", "contact generation", "contact chain walk",
-         "J / W blocks", "K couplings + row constants", "PGS (60 sweeps)", "integrate"]
+         "factorisation A", "diag of M^-1", "joint rows", "contact generation", "contact chain walk (x2)",
+         "row staging + B build (x2)", "(unused)", "PGS (60 sweeps, both envs)", "results + integrate"]
 
 
 def main():
@@ -36,6 +36,7 @@ def main():
     tot = np.zeros(14)
     joint = 0.0
     for t in range(10):
+        dbg.zero_()   # the stamps accumulate over the two per-env solves of a substep
         b.debug_step(hold, obs, dbg)
         torch.cuda.synchronize()
         d = dbg.cpu().numpy()

@@ -5,7 +5,7 @@
 #define TREX_TL 32        /* lanes per env team = half a wavefront */
 #define TREX_MAXD 6       /* tree depth supported */
 #define TREX_MAXCH 4      /* moving children per body */
-#define TREX_MAXC 16      /* contact points kept per env */
+#define TREX_MAXC 13      /* contact points kept per env: 25 motor rows + 3 x 13 contact rows = 64 lanes */
 
 enum TrexParam {
   TP_DT, TP_SUBSTEPS, TP_ITERATIONS, TP_GRAVITY, TP_MOTOR_KP, TP_MOTOR_KD, TP_MOTOR_MAX_FORCE,

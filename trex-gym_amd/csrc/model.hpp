@@ -32,7 +32,7 @@ struct Params {
   double contact_margin = 0.02;     // [EXT]
   double link_damping = 0.04;       // [EXT]
   double max_coordinate_velocity = 100.0;  // [EXT]
-  double max_contacts = 16;
+  double max_contacts = 13;   // 25 motor rows + 3 x 13 contact rows = one row per lane of a wavefront
   double *find(const std::string &name);
 };
 

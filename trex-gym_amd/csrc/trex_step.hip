@@ -28,6 +28,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "device_model.h"
 
 #define TL TREX_TL
@@ -46,7 +48,7 @@
     __builtin_amdgcn_sched_barrier(0);                                                    \
     const unsigned long long _t = __builtin_amdgcn_s_memtime();                           \
     __builtin_amdgcn_s_waitcnt(0xC07F);                                                   \
-    if (DEBUG && args.debug && blockIdx.x == 0 && threadIdx.x == 0) args.debug[3000 + 16 * sub + (i)] = (float)(_t - stamp_last); \
+    if (DEBUG && args.debug && blockIdx.x == 0 && threadIdx.x == 0) args.debug[3000 + 16 * sub + (i)] += (float)(_t - stamp_last); \
     stamp_last = _t;                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                    \
   } while (0)
@@ -81,6 +83,12 @@ __device__ __forceinline__ float tsum(float v) {
   v += dpp_mov<0x140>(v);  // row_mirror
   const unsigned u = __float_as_uint(v);
   const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float wsum(float v) {   // all-reduce over the 64 lanes of the wave
+  v = tsum(v);
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ float tminf(float v) {
@@ -252,15 +260,25 @@ __device__ __forceinline__ void inv21_mul(const float *inv21, const float *v, fl
   }
 }
 
-// ---------------------------------------------------------------- LDS layout (per team)
-constexpr int NJMAX = TL - 7;   // 25 hinge joints at most (26 bodies + 6 base dofs = 32 lanes)
-struct TeamLds {
-  float minv[NJMAX][TL];    // [j-1][dof lane]: column j of M^-1 (motor / limit row responses)       3200 B
-  float4 crow[MAXC * 3];    // contact rows {rhs, 1/diag, K1, K2}, read back as a team-wide broadcast  768 B
-  float aba[TL][28];        // tip-to-base staging: Ia (21) + pa (6) per body; afterwards reused as the
-                            // broadcast stage for the M^-1 columns and the contact blocks        3584 B
+// ---------------------------------------------------------------- LDS layout (per wave = two envs)
+constexpr int NJMAX = TL - 7;            // 25 hinge joints at most (26 bodies + 6 base dofs = 32 lanes)
+constexpr int NROW = NJMAX + 3 * MAXC;   // constraint rows of one env: 25 motor rows + 13 x (normal, 2 friction) = 64
+static_assert(NROW <= 64, "one constraint row per lane");
+// Row descriptors of the env being solved (see "constraint solve" in the kernel). Column side, read as
+// a wave-wide broadcast: chain nodes ca[6] | zc[6] = u/D at those nodes | z0[6] = I0^-1 r0. Own side, read
+// once by the lane that owns the row: u[6] | r0[6] | 1/diag | scaled right-hand side. Record NROW is null.
+struct RowStage {
+  float4 col[NROW + 1][5];    // 20 words per row (2 pad), 16-byte aligned broadcast reads      5200 B
+  float own[NROW + 1][15];    // odd stride: conflict-free per-lane reads                       3900 B
 };
-static_assert(sizeof(float) * TL * 28 >= sizeof(float) * MAXC * 52, "contact stage must fit the aba region");
+struct WaveLds {
+  union {
+    float aba[2][TL][28];     // per team: tip-to-base staging, Ia (21) + pa (6) per body       7168 B
+    RowStage rows;            // afterwards: the row descriptors of the env being solved        9100 B
+  } u;
+  float jcol[NJMAX][64];      // [j-1][row lane]: B entries of motor column j                   6400 B
+};
+static_assert(sizeof(WaveLds) <= 20480, "8 workgroups per CU need <= 20 KB of LDS each");
 
 struct KernelArgs {
   const TrexDeviceModel *model;
@@ -282,10 +300,9 @@ struct KernelArgs {
 // DEBUG = false so that none of the dump's address arithmetic exists in the shipped kernels.
 template <bool RESET, bool DEBUG>
 __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
-  __shared__ TeamLds lds_all[2];
+  __shared__ WaveLds W;
   const int lane = threadIdx.x & (TL - 1);
   const int team = threadIdx.x >> 5;
-  TeamLds &lds = lds_all[team];
   const TrexDeviceModel *__restrict__ M = args.model;
   int env = blockIdx.x * 2 + team;
   const bool env_ok = env < args.n_envs;
@@ -593,7 +610,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
 #pragma unroll
           for (int k = 0; k < 3; k++) pa[k] += dxf[k];
         }
-        float *o = lds.aba[lane];
+        float *o = W.u.aba[team][lane];
 #pragma unroll
         for (int k = 0; k < 6; k++) { o[k] = Ia.A[k]; o[15 + k] = Ia.C[k]; o[21 + k] = pa[k]; }
 #pragma unroll
@@ -605,7 +622,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
         for (int kc = 0; kc < MAXCH; kc++) {
           const int ch = child[kc];
           if (ch >= 0) {
-            const float *o = lds.aba[ch];
+            const float *o = W.u.aba[team][ch];
 #pragma unroll
             for (int k = 0; k < 6; k++) { IA.A[k] += o[k]; IA.C[k] += o[15 + k]; pA[k] += o[21 + k]; }
 #pragma unroll
@@ -727,43 +744,14 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       for (int k = 0; k < 6; k++) A0[k] = is_joint ? -p[k] : ((is_base_dof_s && bdof_s == k) ? 1.f : 0.f);
       inv21_mul(I0inv, A0, g);
     }
-    // response of dof lane to a "row" described by (chain ancestors ca[], z-coefficients zc[], base z0)
-    auto response = [&](const int *ca, const float *zc, const float *z0) -> float {
-      float w = dot6(A0, z0);
-#pragma unroll
-      for (int d = 0; d < MAXD; d++) w += (ca[d] >= 0 && ca[d] == anc[d]) ? Aanc[d] * zc[d] : 0.f;
-      return w;
-    };
+    // Diagonal of M^-1 on the joint lanes (motor / limit rows are unit rows): a^T B a of this lane's own
+    // column of A.
     STAMP(5);
-    // ---- joint columns of M^-1 (response vectors of the motor / limit rows) into REGISTERS:
-    // mcol[j-1] = M^-1[this dof lane][joint j]. Every lane publishes its column of A once (18 floats,
-    // staged in the dead aba region) and reads joint j's as a team-wide LDS broadcast.
-    __syncthreads();
-    {
-      float *o = lds.aba[lane];
-#pragma unroll
-      for (int d = 0; d < MAXD; d++) { o[d] = __int_as_float(anc[d]); o[6 + d] = Z[d]; }
-#pragma unroll
-      for (int k = 0; k < 6; k++) o[12 + k] = g[k];
-    }
-    __syncthreads();
     float mdiag = 1.f;
+    if (is_joint) {
+      mdiag = dot6(A0, g);
 #pragma unroll
-    for (int j = 1; j <= NJMAX; j++) {
-      if (j >= nb) lds.minv[j - 1][lane] = 0.f;
-      if (j < nb) {
-        const float *o = lds.aba[j];
-        int ca[MAXD];
-        float zc[MAXD], z0[6];
-#pragma unroll
-        for (int d = 0; d < MAXD; d++) { ca[d] = __float_as_int(o[d]); zc[d] = o[6 + d]; }
-#pragma unroll
-        for (int k = 0; k < 6; k++) z0[k] = o[12 + k];
-        const float w = response(ca, zc, z0);
-        lds.minv[j - 1][lane] = w;
-        if (ls == j) mdiag = w;
-      }
-      __builtin_amdgcn_sched_barrier(0);   // one column at a time: keeps the staged reads from piling up
+      for (int d = 0; d < MAXD; d++) mdiag += Aanc[d] * Z[d];
     }
 
     STAMP(6);
@@ -961,280 +949,397 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
 
     STAMP2(4);
     STAMP(8);
-    // ---- contact rows: lane c owns point c and walks its body's chain for the three directions
-    //      (normal z, friction x, friction y); everything below is per lane, no reductions.
-    float c_rhs[3] = {0.f, 0.f, 0.f}, c_inv[3] = {0.f, 0.f, 0.f}, c_lam[3] = {0.f, 0.f, 0.f};
-    float c_z0[3][6], c_zc[3][MAXD];
-    int c_anc[MAXD];
-    {
-      const bool has = lane < nc;
-      // updated body velocities (after the unconstrained step) for the row right-hand sides
-      float nvel[6];
-      body_velocities(nw, nv, nqd, nvel);
-      float vb[6];
-#pragma unroll
-      for (int k = 0; k < 6; k++) vb[k] = tshfl(nvel[k], cbody);
-      float p[3][6], diag[3] = {0.f, 0.f, 0.f};
-      const float dirs[3][3] = {{0.f, 0.f, 1.f}, {1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}};
-      float po[3], xrel[3];   // po: the point the forces p[a] refer to (body origin first, then up the chain)
-#pragma unroll
-      for (int k = 0; k < 3; k++) { po[k] = tshfl(r[k], cbody); xrel[k] = cx[k] - po[k]; }
-#pragma unroll
-      for (int a = 0; a < 3; a++) {
-        float xd[3];
-        cross3(xrel, dirs[a], xd);
-#pragma unroll
-        for (int k = 0; k < 3; k++) { p[a][k] = -xd[k]; p[a][3 + k] = -dirs[a][k]; }
-      }
-#pragma unroll
-      for (int d = MAXD; d >= 1; d--) {
-        c_anc[d - 1] = -1;
-#pragma unroll
-        for (int a = 0; a < 3; a++) c_zc[a][d - 1] = 0.f;
-        if (d <= maxdepth) {
-          const int ab = tshfl(anc[d - 1], cbody);
-          c_anc[d - 1] = has ? ab : -1;
-          const int src = ab < 0 ? 0 : ab;
-          float aa[3], Uda[6], ra[3];
-#pragma unroll
-          for (int k = 0; k < 3; k++) { aa[k] = tshfl(S[k], src); ra[k] = tshfl(r[k], src); }
-#pragma unroll
-          for (int k = 0; k < 6; k++) Uda[k] = tshfl(Ud[k], src);
-          const float invDa = tshfl(invD, src);
-          if (has && ab >= 0) {
-            float dd[3];
-#pragma unroll
-            for (int k = 0; k < 3; k++) { dd[k] = po[k] - ra[k]; po[k] = ra[k]; }
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-              float dxf[3];
-              cross3(dd, p[a] + 3, dxf);
-#pragma unroll
-              for (int k = 0; k < 3; k++) p[a][k] += dxf[k];
-              const float ua = -dot3(aa, p[a]);
-              c_zc[a][d - 1] = ua * invDa;
-              diag[a] += ua * ua * invDa;
-#pragma unroll
-              for (int k = 0; k < 6; k++) p[a][k] += Uda[k] * ua;
-            }
-          }
-        }
-      }
-      float pvel[3], wxx[3];
-      cross3(vb, xrel, wxx);   // body velocity is about the body origin
-#pragma unroll
-      for (int k = 0; k < 3; k++) pvel[k] = vb[3 + k] + wxx[k];
-#pragma unroll
-      for (int a = 0; a < 3; a++) {
-        float rhs0[6], dxf[3];
-        cross3(po, p[a] + 3, dxf);   // on to the base origin O
-#pragma unroll
-        for (int k = 0; k < 3; k++) p[a][k] += dxf[k];
-#pragma unroll
-        for (int k = 0; k < 6; k++) rhs0[k] = -p[a][k];
-        inv21_mul(I0inv, rhs0, c_z0[a]);
-        diag[a] += dot6(rhs0, c_z0[a]);
-        c_inv[a] = has ? 1.0f / diag[a] : 0.f;
-        float tv = 0.f;
-        if (a == 0) tv = (cdist > 0.f) ? -cdist * inv_dt : -cdist * cerp * inv_dt;
-        c_rhs[a] = (tv - dot3(dirs[a], pvel)) * c_inv[a];
-      }
-    }
-    STAMP(9);
-    const int ncw = max(nc, __shfl_xor(nc, 32));  // both teams walk the same number of points
-    // The launch lasts as long as its heaviest wave (profiles/r01_v7_sq_counters.md: the mean wave
-    // lives 32 % of it). Let a wave with many contact rows win the issue arbitration against its
-    // lighter SIMD partner: priority = number of 4-point groups it has to sweep.
-    {
-      const int groups = __builtin_amdgcn_readfirstlane((ncw + 3) >> 2);
-      if (groups >= 4) __builtin_amdgcn_s_setprio(3);
-      else if (groups == 3) __builtin_amdgcn_s_setprio(2);
-      else if (groups == 2) __builtin_amdgcn_s_setprio(1);
-      else __builtin_amdgcn_s_setprio(0);
-    }
-    // Per point c (static index -> registers): this dof lane's Jacobian entries Jc[c][a] = velocity of
-    // the point per unit dof rate along normal z / friction x / friction y, and the response Wc[c][a].
-    // Lane c publishes its point (chain, z-coefficients, position, body: 46 floats) in the stage.
-    __syncthreads();
-    if (lane < MAXC) {
-      float *o = reinterpret_cast<float *>(lds.aba) + lane * 52;
-#pragma unroll
-      for (int d = 0; d < MAXD; d++) o[d] = __int_as_float(c_anc[d]);
-#pragma unroll
-      for (int a = 0; a < 3; a++) {
-#pragma unroll
-        for (int d = 0; d < MAXD; d++) o[6 + 6 * a + d] = c_zc[a][d];
-#pragma unroll
-        for (int k = 0; k < 6; k++) o[24 + 6 * a + k] = c_z0[a][k];
-      }
-      o[42] = cx[0]; o[43] = cx[1]; o[44] = cx[2]; o[45] = __int_as_float(cbody);
-    }
-    __syncthreads();
-    const unsigned desc_mask = Mo()->desc_mask[lane];
-    float Jc[MAXC][3], Wc[MAXC][3];
-#pragma unroll
-    for (int c = 0; c < MAXC; c++) {
-#pragma unroll
-      for (int a = 0; a < 3; a++) { Jc[c][a] = 0.f; Wc[c][a] = 0.f; }
-      if (c < ncw) {
-        const float *o = reinterpret_cast<const float *>(lds.aba) + c * 52;
-        int ca[MAXD];
-#pragma unroll
-        for (int d = 0; d < MAXD; d++) ca[d] = __float_as_int(o[d]);
-        const float x[3] = {o[42], o[43], o[44]};
-        const int b = __float_as_int(o[45]);
-        // point velocity per unit dof rate: Sd_lin + Sd_ang x (x - origin of this dof)
-        const float xo[3] = {x[0] - (is_joint ? r[0] : 0.f), x[1] - (is_joint ? r[1] : 0.f), x[2] - (is_joint ? r[2] : 0.f)};
-        float wx[3];
-        cross3(Sd, xo, wx);
-        const bool on = (c < nc) && ((desc_mask >> b) & 1u);
-        Jc[c][0] = on ? Sd[5] + wx[2] : 0.f;
-        Jc[c][1] = on ? Sd[3] + wx[0] : 0.f;
-        Jc[c][2] = on ? Sd[4] + wx[1] : 0.f;
-#pragma unroll
+    // ---- constraint solve: projected Gauss-Seidel in DELASSUS (residual) form, one env at a time on all
+    // 64 lanes. Rows of an env: 25 motor rows (joint j, with the joint's limit row riding on the same lane)
+    // and 3 rows per contact point (normal z, friction x, friction y). Each row s lives on ONE lane and keeps
+    //     y_s = rhs_s - (J_s dv) / diag_s            (its unclamped Gauss-Seidel increment)
+    // so a row visit is  nl = clamp(lam_r + y_r); d = nl - lam_r; lam_r = nl;  y_s += B_sr d  for all s, with
+    // B_sr = -(J_s M^-1 J_r^T)/diag_s (B_rr = -1) - the same iteration as Bullet's dv form (and the oracle's),
+    // but the row's impulse change reaches the other rows as ONE v_readlane (SGPR broadcast) + ONE packed fma
+    // per lane instead of a 32-lane reduction per row: 6-7 instructions per env-row instead of 12 for a
+    // contact row, and a light env no longer walks its wave partner's rows. y (not z = lam + y) is what is
+    // accumulated: it is small where lam is large, and the rounding of a row's own update stays in y.
+    // Rows -> lanes (the same for both envs of the wave; the per-lane inputs of env 1 are brought down
+    // with v_permlane32_swap): motor row j on lane j (1..25); contact row k = 3c+a on lane 32+k for k < 32
+    // and on the seven lanes left in the lower half (0, 26..31) for k = 32..38: 25 + 3 x 13 = 64 rows, one
+    // per lane - which is where the budget of 13 contact points per env comes from.
+    // B comes from the factorisation M^-1 = A^T B A: every row carries a descriptor (chain nodes ca[d],
+    // entries u[d], base force r0; zc = u/D, z0 = I0^-1 r0) and
+    //     J_s M^-1 J_r^T = r0_s . z0_r + sum_d [ca_s[d] == ca_r[d]] u_s[d] zc_r[d].
+    // Motor columns go to LDS (read back one per motor row, and by the dynamic limit rows), contact columns
+    // into registers (static index).
+    float dv = 0.f, nimp = 0.f;
+    const int tid = threadIdx.x;
+    auto krow_lane = [](int k) { return k < 32 ? 32 + k : (k == 32 ? 0 : k - 7); };   // lane of contact row k
+#pragma unroll 1
+    for (int e_ = 0; e_ < 2; e_++) {
+      int e = e_;
+      asm volatile("" : "+s"(e));   // one copy of the solve in the instruction cache, not two
+      // -- contact rows of each team's points: lane c owns point c and walks its body's chain for the
+      //    three directions; per lane, no reductions. (Both teams walk; team e's result is staged.)
+      float c_rhs[3] = {0.f, 0.f, 0.f}, c_inv[3] = {0.f, 0.f, 0.f};
+      float c_z0[3][6], c_zc[3][MAXD], c_u[3][MAXD], c_r0[3][6];
+      int c_anc[MAXD];
+      {
+        const bool has = lane < nc;
+        // updated body velocities (after the unconstrained step) for the row right-hand sides
+        float nvel[6];
+        body_velocities(nw, nv, nqd, nvel);
+        float vb[6];
+  #pragma unroll
+        for (int k = 0; k < 6; k++) vb[k] = tshfl(nvel[k], cbody);
+        float p[3][6], diag[3] = {0.f, 0.f, 0.f};
+        const float dirs[3][3] = {{0.f, 0.f, 1.f}, {1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}};
+        float po[3], xrel[3];   // po: the point the forces p[a] refer to (body origin first, then up the chain)
+  #pragma unroll
+        for (int k = 0; k < 3; k++) { po[k] = tshfl(r[k], cbody); xrel[k] = cx[k] - po[k]; }
+  #pragma unroll
         for (int a = 0; a < 3; a++) {
-          float zc[MAXD], z0[6];
-#pragma unroll
-          for (int d = 0; d < MAXD; d++) zc[d] = o[6 + 6 * a + d];
-#pragma unroll
-          for (int k = 0; k < 6; k++) z0[k] = o[24 + 6 * a + k];
-          Wc[c][a] = (c < nc) ? response(ca, zc, z0) : 0.f;
+          float xd[3];
+          cross3(xrel, dirs[a], xd);
+  #pragma unroll
+          for (int k = 0; k < 3; k++) { p[a][k] = -xd[k]; p[a][3 + k] = -dirs[a][k]; }
         }
-      }
-      __builtin_amdgcn_sched_barrier(0);   // one point at a time
-    }
-    __syncthreads();
-
-    STAMP(10);
-    // Pipelined Gauss-Seidel over the contact rows: the reduction J_r.dv of row r is started two rows
-    // early from the dv of that moment and completed with the scalar couplings K1_r = J_r.W_(r-1),
-    // K2_r = J_r.W_(r-2) once those rows' impulse changes are known - identical arithmetic up to
-    // rounding (J.(dv + d W) = J.dv + d (J.W)), but the dependent chain per row shrinks from
-    // reduce+solve to correct+solve. The all-reduced J.dv is present on every lane, so every lane
-    // finishes the row redundantly: the row constants {rhs, 1/diag, K1, K2} arrive as a team-wide LDS
-    // broadcast prefetched two rows ahead, the impulses are replicated in registers (48 VGPRs), and
-    // nothing has to be broadcast back. No exec branch inside a row; rows run in groups of 4 points
-    // (one basic block each) with the scheduler's window bounded to one point.
-    constexpr int GP = 4, GR = 3 * GP;
-    float c_k1[3] = {0.f, 0.f, 0.f}, c_k2[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int g = 0; g < MAXC / GP; g++) {
-      if (GP * g < ncw) {
-#pragma unroll
-        for (int k = 0; k < GR; k++) {
-          const int r = GR * g + k, c = r / 3, a = r % 3;
-          if (k >= 1) { const float t = tsum(Jc[c][a] * Wc[(r - 1) / 3][(r - 1) % 3]); if (ls == c) c_k1[a] = t; }
-          if (k >= 2) { const float t = tsum(Jc[c][a] * Wc[(r - 2) / 3][(r - 2) % 3]); if (ls == c) c_k2[a] = t; }
-          if (ls == c) lds.crow[r] = (c < nc) ? make_float4(c_rhs[a], c_inv[a], c_k1[a], c_k2[a]) : make_float4(0.f, 0.f, 0.f, 0.f);
-          if (a == 2) __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-    c_lam[0] = c_lam[1] = c_lam[2] = 0.f;
-    __syncthreads();
-    float lam[MAXC][3];   // contact impulses, replicated on every lane of the team
-#pragma unroll
-    for (int c = 0; c < MAXC; c++) { lam[c][0] = 0.f; lam[c][1] = 0.f; lam[c][2] = 0.f; }
-    STAMP(11);
-    float dv = 0.f;
-    const unsigned lim_wave = lim_mask | (unsigned)__shfl_xor((int)lim_mask, 32);
-#if TREX_STAMPS
-    unsigned long long acc_joint = 0, acc_contact = 0;
-#endif
-    for (int it = 0; it < iters; it++) {
-#if TREX_STAMPS
-      __builtin_amdgcn_sched_barrier(0);
-      const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
-      __builtin_amdgcn_s_waitcnt(0xC07F);
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-      int ln = lane;   // opaque once per sweep: `ln == j` is one v_cmp where used, not a spilled mask
-      asm volatile("" : "+v"(ln));
-      // limit rows: only the joints that sit on a stop in either env of the wave (ascending joint
-      // order, as the oracle); j is wave-uniform, so the broadcast is still two v_readlane
-      for (unsigned m = lim_wave; m != 0u; m &= m - 1u) {
-        const int j = __builtin_amdgcn_readfirstlane(__ffs(m) - 1);
-        const float nl = fmaxf(lim_lam + (lim_rhs - lim_dir * dv * inv_mdiag), 0.f);
-        float delta = (nl - lim_lam) * lim_dir;   // lim_dir == 0 on lanes without an active row
-        if (ln == j) lim_lam = nl;
-        delta = tbcast(delta, j);
-        dv += delta * lds.minv[j - 1][lane];
-      }
-#pragma unroll
-      for (int j = 1; j <= NJMAX; j++) {   // joints beyond nb have mot_hi = 0 and a zero column
-        const float nl = __builtin_amdgcn_fmed3f(mot_lam + (mot_rhs - dv * inv_mdiag), -mot_hi, mot_hi);
-        float delta = nl - mot_lam;
-        if (ln == j) mot_lam = nl;
-        delta = tbcast(delta, j);
-        dv += delta * lds.minv[j - 1][lane];
-        if (j % 5 == 0) __builtin_amdgcn_sched_barrier(0);   // prefetch window of 5 columns
-      }
-#if TREX_STAMPS
-      __builtin_amdgcn_sched_barrier(0);
-      const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
-      __builtin_amdgcn_s_waitcnt(0xC07F);
-      __builtin_amdgcn_sched_barrier(0);
-      acc_joint += ts1 - ts0;
-#endif
-#pragma unroll
-      for (int g = 0; g < MAXC / GP; g++) {
-        if (GP * g < ncw) {
-          const int r0 = GR * g;
-          float pa = tsum(Jc[r0 / 3][0] * dv), pb = tsum(Jc[r0 / 3][1] * dv);
-          float4 qa = lds.crow[r0], qb = lds.crow[r0 + 1];
-#pragma unroll
-          for (int k = 0; k < GR; k++) {
-            const int r = r0 + k, c = r / 3, a = r % 3;
-            float pc = 0.f;
-            float4 qc = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k + 2 < GR) {   // rows r, r+1 still missing from this reduction
-              qc = lds.crow[r + 2];
-              pc = tsum(Jc[(r + 2) / 3][(r + 2) % 3] * dv);
+  #pragma unroll
+        for (int d = MAXD; d >= 1; d--) {
+          c_anc[d - 1] = -1;
+  #pragma unroll
+          for (int a = 0; a < 3; a++) { c_zc[a][d - 1] = 0.f; c_u[a][d - 1] = 0.f; }
+          if (d <= maxdepth) {
+            const int ab = tshfl(anc[d - 1], cbody);
+            c_anc[d - 1] = has ? ab : -1;
+            const int src = ab < 0 ? 0 : ab;
+            float aa[3], Uda[6], ra[3];
+  #pragma unroll
+            for (int k = 0; k < 3; k++) { aa[k] = tshfl(S[k], src); ra[k] = tshfl(r[k], src); }
+  #pragma unroll
+            for (int k = 0; k < 6; k++) Uda[k] = tshfl(Ud[k], src);
+            const float invDa = tshfl(invD, src);
+            if (has && ab >= 0) {
+              float dd[3];
+  #pragma unroll
+              for (int k = 0; k < 3; k++) { dd[k] = po[k] - ra[k]; po[k] = ra[k]; }
+  #pragma unroll
+              for (int a = 0; a < 3; a++) {
+                float dxf[3];
+                cross3(dd, p[a] + 3, dxf);
+  #pragma unroll
+                for (int k = 0; k < 3; k++) p[a][k] += dxf[k];
+                const float ua = -dot3(aa, p[a]);
+                c_u[a][d - 1] = ua;
+                c_zc[a][d - 1] = ua * invDa;
+                diag[a] += ua * ua * invDa;
+  #pragma unroll
+                for (int k = 0; k < 6; k++) p[a][k] += Uda[k] * ua;
+              }
             }
-            const float hi = (a == 0) ? 1.0e30f : mu * lam[c][0];
-            const float lo = (a == 0) ? 0.f : -hi;
-            const float nl = __builtin_amdgcn_fmed3f(lam[c][a] + (qa.x - pa * qa.y), lo, hi);
-            const float d = nl - lam[c][a];
-            lam[c][a] = nl;
-            dv += d * Wc[c][a];
-            pb += d * qb.z;                    // K1 of row r+1
-            if (k + 2 < GR) pc += d * qc.w;    // K2 of row r+2
-            pa = pb; pb = pc; qa = qb; qb = qc;
-            if (a == 2) __builtin_amdgcn_sched_barrier(0);  // bound live ranges: one point per window
+          }
+        }
+        float pvel[3], wxx[3];
+        cross3(vb, xrel, wxx);   // body velocity is about the body origin
+  #pragma unroll
+        for (int k = 0; k < 3; k++) pvel[k] = vb[3 + k] + wxx[k];
+  #pragma unroll
+        for (int a = 0; a < 3; a++) {
+          float rhs0[6], dxf[3];
+          cross3(po, p[a] + 3, dxf);   // on to the base origin O
+  #pragma unroll
+          for (int k = 0; k < 3; k++) p[a][k] += dxf[k];
+  #pragma unroll
+          for (int k = 0; k < 6; k++) { rhs0[k] = -p[a][k]; c_r0[a][k] = rhs0[k]; }
+          inv21_mul(I0inv, rhs0, c_z0[a]);
+          diag[a] += dot6(rhs0, c_z0[a]);
+          c_inv[a] = has ? 1.0f / diag[a] : 0.f;
+          float tv = 0.f;
+          if (a == 0) tv = (cdist > 0.f) ? -cdist * inv_dt : -cdist * cerp * inv_dt;
+          c_rhs[a] = (tv - dot3(dirs[a], pvel)) * c_inv[a];
+        }
+      }
+      STAMP(9);
+      const int ncE = __builtin_amdgcn_readlane(nc, 32 * e);
+      const unsigned lmE = (unsigned)__builtin_amdgcn_readlane((int)lim_mask, 32 * e);
+      const float muE = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mu), 32 * e));
+      // per-lane inputs of the motor rows, on lanes 0..31 for either env
+      auto pick = [&](float x) {
+        const unsigned u = __float_as_uint(x);
+        const auto r2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        return __uint_as_float(e ? r2[1] : r2[0]);
+      };
+      const float mhi = pick(mot_hi), ldir = pick(lim_dir), lr = pick(lim_rhs - lim_dir * mot_rhs), mdg = pick(mdiag);
+      // -- stage the row descriptors of env e
+      __syncthreads();
+      if (team == e) {
+        RowStage &S_ = W.u.rows;
+        if (lane >= 1 && lane <= NJMAX) {
+          const int row = lane - 1;
+          const bool jn = is_joint;
+          int ca[MAXD];
+#pragma unroll
+          for (int d = 0; d < MAXD; d++) ca[d] = jn ? anc[d] : -1;
+          S_.col[row][0] = make_float4(__int_as_float(ca[0]), __int_as_float(ca[1]), __int_as_float(ca[2]), __int_as_float(ca[3]));
+          S_.col[row][1] = make_float4(__int_as_float(ca[4]), __int_as_float(ca[5]), jn ? Z[0] : 0.f, jn ? Z[1] : 0.f);
+          S_.col[row][2] = make_float4(jn ? Z[2] : 0.f, jn ? Z[3] : 0.f, jn ? Z[4] : 0.f, jn ? Z[5] : 0.f);
+          S_.col[row][3] = make_float4(jn ? g[0] : 0.f, jn ? g[1] : 0.f, jn ? g[2] : 0.f, jn ? g[3] : 0.f);
+          S_.col[row][4] = make_float4(jn ? g[4] : 0.f, jn ? g[5] : 0.f, 0.f, 0.f);
+          float *o = S_.own[row];
+#pragma unroll
+          for (int d = 0; d < MAXD; d++) { o[d] = jn ? Aanc[d] : 0.f; o[6 + d] = jn ? A0[d] : 0.f; }
+          o[12] = jn ? inv_mdiag : 0.f; o[13] = jn ? mot_rhs : 0.f;
+        }
+        if (lane < MAXC) {
+          const bool has = lane < nc;
+#pragma unroll
+          for (int a = 0; a < 3; a++) {
+            const int row = NJMAX + 3 * lane + a;
+            int ca[MAXD];
+#pragma unroll
+            for (int d = 0; d < MAXD; d++) ca[d] = has ? c_anc[d] : -1;
+            S_.col[row][0] = make_float4(__int_as_float(ca[0]), __int_as_float(ca[1]), __int_as_float(ca[2]), __int_as_float(ca[3]));
+            S_.col[row][1] = make_float4(__int_as_float(ca[4]), __int_as_float(ca[5]), has ? c_zc[a][0] : 0.f, has ? c_zc[a][1] : 0.f);
+            S_.col[row][2] = make_float4(has ? c_zc[a][2] : 0.f, has ? c_zc[a][3] : 0.f, has ? c_zc[a][4] : 0.f, has ? c_zc[a][5] : 0.f);
+            S_.col[row][3] = make_float4(has ? c_z0[a][0] : 0.f, has ? c_z0[a][1] : 0.f, has ? c_z0[a][2] : 0.f, has ? c_z0[a][3] : 0.f);
+            S_.col[row][4] = make_float4(has ? c_z0[a][4] : 0.f, has ? c_z0[a][5] : 0.f, 0.f, 0.f);
+            float *o = S_.own[row];
+#pragma unroll
+            for (int d = 0; d < MAXD; d++) { o[d] = has ? c_u[a][d] : 0.f; o[6 + d] = has ? c_r0[a][d] : 0.f; }
+            o[12] = has ? c_inv[a] : 0.f; o[13] = has ? c_rhs[a] : 0.f;
+          }
+        }
+        if (lane == 31) {   // the null record
+          const float m1 = __int_as_float(-1);
+          S_.col[NROW][0] = make_float4(m1, m1, m1, m1);
+          S_.col[NROW][1] = make_float4(m1, m1, 0.f, 0.f);
+          S_.col[NROW][2] = make_float4(0.f, 0.f, 0.f, 0.f);
+          S_.col[NROW][3] = make_float4(0.f, 0.f, 0.f, 0.f);
+          S_.col[NROW][4] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int k = 0; k < 15; k++) S_.own[NROW][k] = 0.f;
+        }
+      }
+      __syncthreads();
+      // -- this lane's row
+      int row0 = NROW;
+      if (tid >= 1 && tid <= NJMAX) row0 = tid - 1;
+      else if (tid >= 32) row0 = NJMAX + (tid - 32);
+      else row0 = NJMAX + 32 + (tid == 0 ? 0 : tid - 25);   // lanes 0, 26..31 -> contact rows 32..38
+      int ca0[MAXD];
+      float u0[MAXD], r00[6], inv0, y, lam = 0.f;
+      {
+        const float *c = reinterpret_cast<const float *>(W.u.rows.col[row0]);
+        const float *o = W.u.rows.own[row0];
+#pragma unroll
+        for (int d = 0; d < MAXD; d++) { ca0[d] = __float_as_int(c[d]); u0[d] = o[d]; r00[d] = o[6 + d]; }
+        inv0 = o[12]; y = o[13];
+      }
+      auto read_col = [&](int row, int *car, float *zcr, float *z0r) {
+        const float4 *c4 = W.u.rows.col[row];
+        const float4 q0 = c4[0], q1 = c4[1], q2 = c4[2], q3 = c4[3], q4 = c4[4];
+        car[0] = __float_as_int(q0.x); car[1] = __float_as_int(q0.y); car[2] = __float_as_int(q0.z); car[3] = __float_as_int(q0.w);
+        car[4] = __float_as_int(q1.x); car[5] = __float_as_int(q1.y);
+        zcr[0] = q1.z; zcr[1] = q1.w; zcr[2] = q2.x; zcr[3] = q2.y; zcr[4] = q2.z; zcr[5] = q2.w;
+        z0r[0] = q3.x; z0r[1] = q3.y; z0r[2] = q3.z; z0r[3] = q3.w; z0r[4] = q4.x; z0r[5] = q4.y;
+      };
+      // -- motor columns -> LDS (unused chain slots hold u = zc = 0, so a -1 == -1 match adds nothing)
+#pragma unroll 5
+      for (int k = 0; k < NJMAX; k++) {
+        int car[MAXD];
+        float zcr[MAXD], z0r[6];
+        read_col(k, car, zcr, z0r);
+        float a0_ = dot6(r00, z0r);
+#pragma unroll
+        for (int d = 0; d < MAXD; d++) a0_ += (ca0[d] == car[d]) ? u0[d] * zcr[d] : 0.f;
+        W.jcol[k][tid] = -inv0 * a0_;
+      }
+      // -- contact columns -> registers
+      float Bc[3 * MAXC];
+#pragma unroll
+      for (int c = 0; c < MAXC; c++) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) Bc[3 * c + a] = 0.f;
+        if (c < ncE) {
+          float m0[MAXD];
+#pragma unroll
+          for (int a = 0; a < 3; a++) {
+            const int k = 3 * c + a;
+            int car[MAXD];
+            float zcr[MAXD], z0r[6];
+            read_col(NJMAX + k, car, zcr, z0r);
+            if (a == 0) {
+#pragma unroll
+              for (int d = 0; d < MAXD; d++) m0[d] = (ca0[d] == car[d]) ? u0[d] : 0.f;
+            }
+            float a0_ = dot6(r00, z0r);
+#pragma unroll
+            for (int d = 0; d < MAXD; d++) a0_ += m0[d] * zcr[d];
+            Bc[k] = -inv0 * a0_;
           }
         }
       }
-    }
+      __syncthreads();
+      // motor columns back into registers for the sweeps (the LDS copy serves the dynamic limit rows)
+      float Bm[NJMAX];
 #pragma unroll
-    for (int c = 0; c < MAXC; c++)
-      if (ls == c) { c_lam[0] = lam[c][0]; c_lam[1] = lam[c][1]; c_lam[2] = lam[c][2]; }
+      for (int j = 0; j < NJMAX; j++) Bm[j] = W.jcol[j][tid];
+      STAMP(10);
+      // The launch lasts as long as its heaviest wave: let a wave with many rows win the issue arbitration
+      // against its lighter SIMD partner.
+      {
+        const int groups = (ncE + 3) >> 2;
+        if (groups >= 4) __builtin_amdgcn_s_setprio(3);
+        else if (groups == 3) __builtin_amdgcn_s_setprio(2);
+        else if (groups == 2) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+      }
+      float lim_lam = 0.f;
 #if TREX_STAMPS
-    if (DEBUG && args.debug && blockIdx.x == 0 && threadIdx.x == 0) {
-      args.debug[3000 + 16 * sub + 14] = (float)acc_joint;
-      args.debug[3000 + 16 * sub + 15] = (float)lim_wave;
-    }
+      unsigned long long acc_joint = 0;
 #endif
-    __syncthreads();
-    STAMP(12);
-
+      constexpr int GP = 4;
+      for (int it = 0; it < iters; it++) {
+#if TREX_STAMPS
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        int vs = tid;   // opaque once per sweep: `vs == j` is one v_cmp where used, not a spilled mask
+        asm volatile("" : "+v"(vs));
+        // limit rows (ascending joint order, as the oracle): the row of joint j rides on motor lane j,
+        // whose y gives dv_j / diag = rhs - y
+        for (unsigned m = lmE; m != 0u; m &= m - 1u) {
+          const int j = __ffs(m) - 1;
+          const float nl = fmaxf(lim_lam + (lr + ldir * y), 0.f);
+          const float dl = (nl - lim_lam) * ldir;
+          if (vs == j) lim_lam = nl;
+          const float sd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dl), j));
+          y += W.jcol[j - 1][tid] * sd;
+        }
+#pragma unroll
+        for (int j = 1; j <= NJMAX; j++) {   // joints beyond nb are null rows (y = 0, bounds 0)
+          const float nl = __builtin_amdgcn_fmed3f(lam + y, -mhi, mhi);
+          const float d = nl - lam;
+          const float sd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), j));
+          if (vs == j) lam = nl;
+          y += Bm[j - 1] * sd;
+        }
+#if TREX_STAMPS
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_sched_barrier(0);
+        acc_joint += ts1 - ts0;
+#endif
+#pragma unroll
+        for (int g = 0; g < (MAXC + GP - 1) / GP; g++) {
+          if (GP * g < ncE) {
+#pragma unroll
+            for (int cc = 0; cc < GP; cc++) {
+              const int c = GP * g + cc;
+              if (c >= MAXC) continue;
+              float hi = 0.f;
+#pragma unroll
+              for (int a = 0; a < 3; a++) {
+                const int k = 3 * c + a;
+                const int L = krow_lane(k);
+                float nl;
+                if (a == 0) nl = fmaxf(lam + y, 0.f);
+                else nl = __builtin_amdgcn_fmed3f(lam + y, -hi, hi);
+                const float d = nl - lam;
+                const float sd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), L));
+                if (a == 0) hi = muE * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nl), L));
+                if (vs == L) lam = nl;
+                y += Bc[k] * sd;
+              }
+              __builtin_amdgcn_sched_barrier(0);   // bound live ranges: one point per window
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      STAMP(12);
+#if TREX_STAMPS
+      if (DEBUG && args.debug && blockIdx.x == 0 && threadIdx.x == 0) {
+        args.debug[3000 + 16 * sub + 14] += (float)acc_joint;
+        args.debug[3000 + 16 * sub + 15] = (float)lmE;
+      }
+#endif
+      // -- results of env e. Joint lanes: dv_j / diag_j = -sum_r B_jr lam_r, summed afresh from the final
+      // impulses (rhs_j - y_j holds the same number, but as a difference of large terms when the motor is
+      // saturated). Base twist change = sum_r lam_r z0_r.
+      const bool mrow = tid >= 1 && tid <= NJMAX;
+      const float lt0 = lam + (mrow ? ldir * lim_lam : 0.f);   // motor + limit impulse of the joint
+      float dvj = 0.f;
+#pragma unroll
+      for (int j = 1; j <= NJMAX; j++) {
+        const float sl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lt0), j));
+        dvj -= Bm[j - 1] * sl;
+      }
+#pragma unroll
+      for (int g = 0; g < (MAXC + 3) / 4; g++) {
+        if (4 * g < ncE) {
+#pragma unroll
+          for (int k = 12 * g; k < 12 * g + 12 && k < 3 * MAXC; k++) {
+            const float sl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lam), krow_lane(k)));
+            dvj -= Bc[k] * sl;
+          }
+        }
+      }
+      float dvb[6];
+      {
+        const float *c0 = reinterpret_cast<const float *>(W.u.rows.col[row0]);
+#pragma unroll
+        for (int k = 0; k < 6; k++) dvb[k] = wsum(lt0 * c0[12 + k]);
+      }
+      const bool nrm0 = !mrow && (row0 - NJMAX) % 3 == 0;
+      const float ni = wsum(nrm0 ? lam : 0.f);
+      {
+        // lanes 0..31 hold env e's joint results; every lane takes those of its own index within the team
+        float dlo = dvj * mdg;
+        {
+          const unsigned u = __float_as_uint(dlo);
+          const auto r2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+          dlo = __uint_as_float(r2[0]);
+        }
+        float mlo = lam;
+        {
+          const unsigned u = __float_as_uint(mlo);
+          const auto r2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+          mlo = __uint_as_float(r2[0]);
+        }
+        if (team == e) {
+          dv = is_joint ? dlo : 0.f;
+#pragma unroll
+          for (int k = 0; k < 6; k++)
+            if (is_base_dof_s && bdof_s == k) dv = dvb[k];
+          mot_lam = mlo;
+          nimp = ni;
+        }
+      }
+      if (DEBUG && args.debug && blockIdx.x == 0 && e == 0) {
+        float *D = args.debug;
+        // joint block of M^-1 recovered from the staged columns, contact impulses by row
+        if (team == 0) {
+#pragma unroll
+          for (int j = 1; j <= NJMAX; j++) D[160 + 32 * (j - 1) + lane] = is_joint ? -W.jcol[j - 1][lane] * mdiag : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 3 * MAXC; k++) {
+          const float l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lam), krow_lane(k)));
+          if (threadIdx.x == 0 && k / 3 < ncE) D[960 + (k / 3) * 16 + 11 + k % 3] = l;
+        }
+      }
+      __syncthreads();
+    }
 
     if (DEBUG && args.debug && blockIdx.x == 0 && team == 0) {
       float *D = args.debug;
       D[lane] = qdd; D[64 + lane] = vg; D[96 + lane] = dv;
       if (lane < 6) D[32 + lane] = a0[lane];
       if (lane == 0) { D[128] = (float)nc; D[129] = (float)lim_mask; }
-#pragma unroll
-      for (int j = 1; j <= NJMAX; j++) D[160 + 32 * (j - 1) + lane] = lds.minv[j - 1][lane];
       if (lane < nc) {
         float *C = D + 960 + lane * 16;
         C[0] = (float)cbody; C[1] = cx[0]; C[2] = cx[1]; C[3] = cx[2]; C[4] = cdist;
-#pragma unroll
-        for (int a = 0; a < 3; a++) { C[5 + a] = c_inv[a]; C[8 + a] = c_rhs[a]; C[11 + a] = c_lam[a]; }
       }
-#pragma unroll
-      for (int c = 0; c < MAXC; c++)
-        if (c < nc)
-          for (int a = 0; a < 3; a++) D[1216 + (c * 3 + a) * 32 + lane] = Wc[c][a];
     }
     __syncthreads();
 
@@ -1263,7 +1368,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
 #pragma unroll
       for (int k = 0; k < 4; k++) quat[k] = o[k] * qn;
       stat_nc = nc;
-      stat_imp = tsum(lane < nc ? c_lam[0] : 0.f);
+      stat_imp = nimp;
     }
     STAMP(13);
   }
@@ -1521,6 +1626,6 @@ hipError_t trex_launch_copy_mass_scale(const float *src, float *dst, int n, int 
   return hipGetLastError();
 }
 
-int trex_step_lds_bytes(void) { return (int)(2 * sizeof(TeamLds)); }
+int trex_step_lds_bytes(void) { return (int)sizeof(WaveLds); }
 
 }  // extern "C"
