@@ -264,19 +264,23 @@ __device__ __forceinline__ void inv21_mul(const float *inv21, const float *v, fl
 constexpr int NJMAX = TL - 7;            // 25 hinge joints at most (26 bodies + 6 base dofs = 32 lanes)
 constexpr int NROW = NJMAX + 3 * MAXC;   // constraint rows of one env: 25 motor rows + 13 x (normal, 2 friction) = 64
 static_assert(NROW <= 64, "one constraint row per lane");
-// Row descriptors of the env being solved (see "constraint solve" in the kernel). Column side, read as
-// a wave-wide broadcast: chain nodes ca[6] | zc[6] = u/D at those nodes | z0[6] = I0^-1 r0. Own side, read
-// once by the lane that owns the row: u[6] | r0[6] | 1/diag | scaled right-hand side. Record NROW is null.
+// Row descriptors. Column side, read as a wave-wide broadcast: chain nodes ca[6] | zc[6] = u/D at those
+// nodes | z0[6] = I0^-1 r0. Own side, read once by the lane that owns the row: u[6] | r0[6] | 1/diag | scaled
+// right-hand side. Records: motor rows of env 0, motor rows of env 1 (staged once per substep, straight
+// after the factorisation), contact rows of the env being solved, one null record.
+constexpr int CROW0 = 2 * NJMAX;            // first contact record
+constexpr int NREC = CROW0 + 3 * MAXC + 1;  // 90 records, the last one null
 struct RowStage {
-  float4 col[NROW + 1][5];    // 20 words per row (2 pad), 16-byte aligned broadcast reads      5200 B
-  float own[NROW + 1][15];    // odd stride: conflict-free per-lane reads                       3900 B
+  float4 col[NREC][5];        // 20 words per row (2 pad), 16-byte aligned broadcast reads      7200 B
+  float own[NREC][15];        // odd stride: conflict-free per-lane reads                       5400 B
 };
 struct WaveLds {
   union {
     float aba[2][TL][28];     // per team: tip-to-base staging, Ia (21) + pa (6) per body       7168 B
-    RowStage rows;            // afterwards: the row descriptors of the env being solved        9100 B
+    RowStage rows;            // afterwards: the row descriptors                               12600 B
   } u;
   float jcol[NJMAX][64];      // [j-1][row lane]: B entries of motor column j                   6400 B
+  float i0inv[2][24];         // per team: inverse of the base's articulated inertia (21)        192 B
 };
 static_assert(sizeof(WaveLds) <= 20480, "8 workgroups per CU need <= 20 KB of LDS each");
 
@@ -645,6 +649,12 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
 #pragma unroll
       for (int k = 0; k < 6; k++) p0[k] = -tshfl(pA[k], 0);
       inv21_mul(I0inv, p0, a0);
+      if (lane < 21) {   // parked for the contact rows: not carried in registers across contact generation
+        float v = I0inv[0];
+#pragma unroll
+        for (int k = 1; k < 21; k++) v = (lane == k) ? I0inv[k] : v;
+        W.i0inv[team][lane] = v;
+      }
     }
     STAMP(3);
     // ---- ABA pass 3 (base to tip): accelerations
@@ -970,6 +980,28 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
     // into registers (static index).
     float dv = 0.f, nimp = 0.f;
     const int tid = threadIdx.x;
+    // motor rows of both envs: staged once, so that the factorisation's per-lane column data (Aanc, Z, A0,
+    // g) is dead before the solves
+    __syncthreads();
+    {
+      RowStage &S_ = W.u.rows;
+      if (lane >= 1 && lane <= NJMAX) {
+        const int row = team * NJMAX + lane - 1;
+        const bool jn = is_joint;
+        int ca[MAXD];
+#pragma unroll
+        for (int d = 0; d < MAXD; d++) ca[d] = jn ? anc[d] : -1;
+        S_.col[row][0] = make_float4(__int_as_float(ca[0]), __int_as_float(ca[1]), __int_as_float(ca[2]), __int_as_float(ca[3]));
+        S_.col[row][1] = make_float4(__int_as_float(ca[4]), __int_as_float(ca[5]), jn ? Z[0] : 0.f, jn ? Z[1] : 0.f);
+        S_.col[row][2] = make_float4(jn ? Z[2] : 0.f, jn ? Z[3] : 0.f, jn ? Z[4] : 0.f, jn ? Z[5] : 0.f);
+        S_.col[row][3] = make_float4(jn ? g[0] : 0.f, jn ? g[1] : 0.f, jn ? g[2] : 0.f, jn ? g[3] : 0.f);
+        S_.col[row][4] = make_float4(jn ? g[4] : 0.f, jn ? g[5] : 0.f, 0.f, 0.f);
+        float *o = S_.own[row];
+#pragma unroll
+        for (int d = 0; d < MAXD; d++) { o[d] = jn ? Aanc[d] : 0.f; o[6 + d] = jn ? A0[d] : 0.f; }
+        o[12] = jn ? inv_mdiag : 0.f; o[13] = jn ? mot_rhs : 0.f;
+      }
+    }
     auto krow_lane = [](int k) { return k < 32 ? 32 + k : (k == 32 ? 0 : k - 7); };   // lane of contact row k
 #pragma unroll 1
     for (int e_ = 0; e_ < 2; e_++) {
@@ -1037,6 +1069,9 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
         }
         float pvel[3], wxx[3];
         cross3(vb, xrel, wxx);   // body velocity is about the body origin
+        float I0l[21];
+#pragma unroll
+        for (int k = 0; k < 21; k++) I0l[k] = W.i0inv[team][k];
   #pragma unroll
         for (int k = 0; k < 3; k++) pvel[k] = vb[3 + k] + wxx[k];
   #pragma unroll
@@ -1047,7 +1082,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
           for (int k = 0; k < 3; k++) p[a][k] += dxf[k];
   #pragma unroll
           for (int k = 0; k < 6; k++) { rhs0[k] = -p[a][k]; c_r0[a][k] = rhs0[k]; }
-          inv21_mul(I0inv, rhs0, c_z0[a]);
+          inv21_mul(I0l, rhs0, c_z0[a]);
           diag[a] += dot6(rhs0, c_z0[a]);
           c_inv[a] = has ? 1.0f / diag[a] : 0.f;
           float tv = 0.f;
@@ -1070,27 +1105,11 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       __syncthreads();
       if (team == e) {
         RowStage &S_ = W.u.rows;
-        if (lane >= 1 && lane <= NJMAX) {
-          const int row = lane - 1;
-          const bool jn = is_joint;
-          int ca[MAXD];
-#pragma unroll
-          for (int d = 0; d < MAXD; d++) ca[d] = jn ? anc[d] : -1;
-          S_.col[row][0] = make_float4(__int_as_float(ca[0]), __int_as_float(ca[1]), __int_as_float(ca[2]), __int_as_float(ca[3]));
-          S_.col[row][1] = make_float4(__int_as_float(ca[4]), __int_as_float(ca[5]), jn ? Z[0] : 0.f, jn ? Z[1] : 0.f);
-          S_.col[row][2] = make_float4(jn ? Z[2] : 0.f, jn ? Z[3] : 0.f, jn ? Z[4] : 0.f, jn ? Z[5] : 0.f);
-          S_.col[row][3] = make_float4(jn ? g[0] : 0.f, jn ? g[1] : 0.f, jn ? g[2] : 0.f, jn ? g[3] : 0.f);
-          S_.col[row][4] = make_float4(jn ? g[4] : 0.f, jn ? g[5] : 0.f, 0.f, 0.f);
-          float *o = S_.own[row];
-#pragma unroll
-          for (int d = 0; d < MAXD; d++) { o[d] = jn ? Aanc[d] : 0.f; o[6 + d] = jn ? A0[d] : 0.f; }
-          o[12] = jn ? inv_mdiag : 0.f; o[13] = jn ? mot_rhs : 0.f;
-        }
         if (lane < MAXC) {
           const bool has = lane < nc;
 #pragma unroll
           for (int a = 0; a < 3; a++) {
-            const int row = NJMAX + 3 * lane + a;
+            const int row = CROW0 + 3 * lane + a;
             int ca[MAXD];
 #pragma unroll
             for (int d = 0; d < MAXD; d++) ca[d] = has ? c_anc[d] : -1;
@@ -1107,21 +1126,21 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
         }
         if (lane == 31) {   // the null record
           const float m1 = __int_as_float(-1);
-          S_.col[NROW][0] = make_float4(m1, m1, m1, m1);
-          S_.col[NROW][1] = make_float4(m1, m1, 0.f, 0.f);
-          S_.col[NROW][2] = make_float4(0.f, 0.f, 0.f, 0.f);
-          S_.col[NROW][3] = make_float4(0.f, 0.f, 0.f, 0.f);
-          S_.col[NROW][4] = make_float4(0.f, 0.f, 0.f, 0.f);
+          S_.col[NREC - 1][0] = make_float4(m1, m1, m1, m1);
+          S_.col[NREC - 1][1] = make_float4(m1, m1, 0.f, 0.f);
+          S_.col[NREC - 1][2] = make_float4(0.f, 0.f, 0.f, 0.f);
+          S_.col[NREC - 1][3] = make_float4(0.f, 0.f, 0.f, 0.f);
+          S_.col[NREC - 1][4] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-          for (int k = 0; k < 15; k++) S_.own[NROW][k] = 0.f;
+          for (int k = 0; k < 15; k++) S_.own[NREC - 1][k] = 0.f;
         }
       }
       __syncthreads();
       // -- this lane's row
-      int row0 = NROW;
-      if (tid >= 1 && tid <= NJMAX) row0 = tid - 1;
-      else if (tid >= 32) row0 = NJMAX + (tid - 32);
-      else row0 = NJMAX + 32 + (tid == 0 ? 0 : tid - 25);   // lanes 0, 26..31 -> contact rows 32..38
+      int row0;
+      if (tid >= 1 && tid <= NJMAX) row0 = e * NJMAX + tid - 1;
+      else if (tid >= 32) row0 = CROW0 + (tid - 32);
+      else row0 = CROW0 + 32 + (tid == 0 ? 0 : tid - 25);   // lanes 0, 26..31 -> contact rows 32..38
       int ca0[MAXD];
       float u0[MAXD], r00[6], inv0, y, lam = 0.f;
       {
@@ -1144,7 +1163,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       for (int k = 0; k < NJMAX; k++) {
         int car[MAXD];
         float zcr[MAXD], z0r[6];
-        read_col(k, car, zcr, z0r);
+        read_col(e * NJMAX + k, car, zcr, z0r);
         float a0_ = dot6(r00, z0r);
 #pragma unroll
         for (int d = 0; d < MAXD; d++) a0_ += (ca0[d] == car[d]) ? u0[d] * zcr[d] : 0.f;
@@ -1163,7 +1182,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
             const int k = 3 * c + a;
             int car[MAXD];
             float zcr[MAXD], z0r[6];
-            read_col(NJMAX + k, car, zcr, z0r);
+            read_col(CROW0 + k, car, zcr, z0r);
             if (a == 0) {
 #pragma unroll
               for (int d = 0; d < MAXD; d++) m0[d] = (ca0[d] == car[d]) ? u0[d] : 0.f;
@@ -1290,7 +1309,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
 #pragma unroll
         for (int k = 0; k < 6; k++) dvb[k] = wsum(lt0 * c0[12 + k]);
       }
-      const bool nrm0 = !mrow && (row0 - NJMAX) % 3 == 0;
+      const bool nrm0 = !mrow && (row0 - CROW0) % 3 == 0;
       const float ni = wsum(nrm0 ? lam : 0.f);
       {
         // lanes 0..31 hold env e's joint results; every lane takes those of its own index within the team
