@@ -64,8 +64,7 @@ def compare_substep(name, state63, motors_on, target=None):
     for j in range(1, nb):
         col = D[160 + 32 * (j - 1): 160 + 32 * j]
         minv_g[6 + np.arange(nj), 6 + j - 1] = col[1:nb]
-        minv_g[0:6, 6 + j - 1] = col[nb:nb + 6]
-    print(" Minv joint columns rel err %.2e" % rel(minv_g[:, 6:], minv_o[:, 6:]))
+    print(" Minv joint block rel err %.2e" % rel(minv_g[6:, 6:], minv_o[6:, 6:]))
     nc = int(D[128])
     bo, lo, po, do = orc.contacts(s)
     print(" contacts gpu %d oracle %d" % (nc, len(bo)))

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""How long does each wave of a step launch live, and why? Diagnostic build (make stamps): every wave
+writes its s_memtime duration and the contact counts of its two envs. Bench scenario (uniform random
+actions), 4096 envs, with and without the contact-count pairing (TREX_DEBUG_PAIR=1)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+os.environ.setdefault("TREX_LIB", os.path.join(ROOT, "trex-gym_amd", "trex_gym", "libtrex_hip_stamps.so"))
+sys.path.insert(0, os.path.join(ROOT, "trex-gym_amd"))
+from trex_gym import _capi, sharding  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda:0")
+    n = 4096
+    m = _capi.Model()
+    b = _capi.Batch(m, n)
+    obs = torch.zeros(n, 75, device=dev); rew = torch.zeros(n, device=dev); done = torch.zeros(n, dtype=torch.uint8, device=dev)
+    b.reset(obs)
+    lo = torch.tensor(m.lower, dtype=torch.float32, device=dev); hi = torch.tensor(m.upper, dtype=torch.float32, device=dev)
+    ids = torch.arange(n, device=dev)
+    for t in range(int(sys.argv[1]) if len(sys.argv) > 1 else 230):
+        a = sharding.synthetic_actions(ids, t, lo, hi, device=dev)
+        b.step(a, obs, rew, done)
+    dbg = torch.zeros(3 * 4096, device=dev)
+    a = sharding.synthetic_actions(ids, 1000, lo, hi, device=dev)
+    b.debug_step(a, obs, dbg)
+    torch.cuda.synchronize()
+    d = dbg.cpu().numpy()
+    cyc = d[4096:4096 + n // 2]
+    code = d[8192:8192 + n // 2].astype(int)
+    n0, n1 = code % 100, code // 100
+    tot = n0 + n1
+    print("pairing in this launch:", "on" if os.environ.get("TREX_DEBUG_PAIR") else "off")
+    print("wave cycles: mean %.3g  median %.3g  p90 %.3g  p99 %.3g  max %.3g  (max/mean %.2f)"
+          % (cyc.mean(), np.median(cyc), np.percentile(cyc, 90), np.percentile(cyc, 99), cyc.max(), cyc.max() / cyc.mean()))
+    print("contacts per wave (sum of the two envs): mean %.1f max %d" % (tot.mean(), tot.max()))
+    for lo_, hi_ in ((0, 0), (1, 4), (5, 8), (9, 12), (13, 16), (17, 26)):
+        sel = (tot >= lo_) & (tot <= hi_)
+        if sel.any():
+            print("  waves with %2d..%2d contacts: %4d  cycles mean %.3g  max %.3g" % (lo_, hi_, sel.sum(), cyc[sel].mean(), cyc[sel].max()))
+    k = np.argsort(-cyc)[:8]
+    print("slowest waves (cycles, contacts env a, env b):", [(int(cyc[i]), int(n0[i]), int(n1[i])) for i in k])
+
+
+if __name__ == "__main__":
+    main()

@@ -308,6 +308,7 @@ int trex_batch_create(const TrexModel *model, int num_envs, int device, TrexBatc
   A(n, (void **)&b->arr.motors_on);
   A(n * sizeof(int32_t), (void **)&b->arr.contact_count);
   A(n * sizeof(float), (void **)&b->arr.normal_impulse);
+  A(n * sizeof(int32_t), (void **)&b->arr.pair_perm);
   size_t nv = model->host.hull_xyz.size();
   A((nv ? nv : 1) * sizeof(float4), (void **)&b->arr.hull);
   const size_t nl = model->host.link_names.size();

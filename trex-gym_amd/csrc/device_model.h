@@ -41,6 +41,7 @@ struct TrexBatchArrays {
   uint8_t *motors_on;
   int32_t *contact_count;
   float *normal_impulse;
+  int32_t *pair_perm;     /* [N] wave slot -> env id: envs sorted by last contact count, lightest paired with heaviest */
   float4 *hull;  /* [nv] body-frame collision points: xyz + support radius (0 for hull vertices) */
   int num_links;
   const int *link_body;   /* [L] body of each URDF link */

@@ -6,10 +6,11 @@
 // (trex_env.py:186-196); with RESET: TrexBulletEnv.reset() (trex_env.py:98-122).
 //
 // Mapping to the hardware
-//   * one 64-lane wavefront = one workgroup = TWO envs, one per 32-lane half ("team"): the tree has
-//     26 bodies and 25 + 6 = 31 degrees of freedom, so a team's lanes are (a) the bodies 0..25 for the
-//     tree sweeps and (b) the dofs for the constraint solve: lanes 1..25 = joint of that body,
-//     lanes 26..31 = base angular xyz / linear xyz.  No inter-wave synchronisation exists.
+//   * one 64-lane wavefront = one workgroup = TWO envs. Tree phases: one env per 32-lane half ("team"):
+//     the tree has 26 bodies and 25 + 6 = 31 degrees of freedom, so a team's lanes are the bodies 0..25
+//     (lanes 1..25 = joint of that body, lanes 26..31 = base angular xyz / linear xyz for the
+//     factorisation). Constraint solve: one env at a time on all 64 lanes, ONE CONSTRAINT ROW PER LANE
+//     (25 motor rows + 3 x 13 contact rows = 64).  No inter-wave synchronisation exists.
 //   * every spatial quantity is expressed in WORLD-ALIGNED axes about the body's OWN frame origin
 //     (the joint axis passes through it). Parent<->child sweeps therefore need no rotations - only
 //     the translation by the joint offset d - and, unlike a single common origin, no quantity is a
@@ -17,16 +18,18 @@
 //     6..12 registers per level with wavefront shuffles (ds_bpermute within the half), the
 //     tip-to-base articulated-inertia pass stages 27 floats per body through LDS.
 //   * M^-1 is never formed by repeated sweeps: the ABA factorisation M^-1 = A^T B A is kept
-//     DISTRIBUTED (lane j holds column j of A: <= 6 ancestor entries + 6 base entries), which makes
-//     every constraint row's response vector a handful of FMAs.
-//   * projected Gauss-Seidel runs on the velocity level with dv spread over the dof lanes; joint
-//     rows (limits, motors) have unit Jacobians, so only contact rows need a cross-lane reduction.
+//     DISTRIBUTED (lane j holds column j of A: <= 6 ancestor entries + 6 base entries); any entry of
+//     the Delassus matrix J M^-1 J^T is then 12 multiply-adds of two row descriptors.
+//   * projected Gauss-Seidel runs in Delassus (residual) form: a row's impulse change reaches all other
+//     rows as one v_readlane (SGPR broadcast) + one FMA per lane - no reduction, no LDS in a row.
 //   * HBM traffic per env-step is the state row in/out + action in + obs/reward out (912 B); the
-//     kernel is latency/VALU bound, not bandwidth bound.
+//     kernel is bound by the instruction issue of its heaviest wave, not by bandwidth.
 //
 // The arithmetic is the one restated by oracle/trex_oracle.c; tests/ compare the two.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -294,6 +297,7 @@ struct KernelArgs {
   uint8_t *done;          // [N] nullable
   float *penalties;       // [N, 3] nullable
   const uint8_t *reset_mask;  // RESET only, nullable = all
+  const int32_t *perm;        // wave slot -> env id (step launches), nullable = identity
   float w_distance, w_energy, w_drift;
   float *debug;           // diagnostics of env 0's last substep (tests), nullable
 };
@@ -305,12 +309,16 @@ struct KernelArgs {
 template <bool RESET, bool DEBUG>
 __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
   __shared__ WaveLds W;
+#if TREX_STAMPS
+  const unsigned long long wave_t0 = __builtin_amdgcn_s_memtime();
+#endif
   const int lane = threadIdx.x & (TL - 1);
   const int team = threadIdx.x >> 5;
   const TrexDeviceModel *__restrict__ M = args.model;
-  int env = blockIdx.x * 2 + team;
+  int env = blockIdx.x * 2 + team;   // wave slot
   const bool env_ok = env < args.n_envs;
   if (!env_ok) env = args.n_envs - 1;  // duplicate the last env's work, never store it
+  if (args.perm) env = args.perm[env];
 
   const int nb = M->nb, maxdepth = M->maxdepth;
   const float dt = M->prm[TP_DT];
@@ -1221,6 +1229,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       STAMP(10);
       // The launch lasts as long as its heaviest wave: let a wave with many rows win the issue arbitration
       // against its lighter SIMD partner.
+#ifndef TREX_NO_PRIO
       {
         const int groups = (ncE + 3) >> 2;
         if (groups >= 4) __builtin_amdgcn_s_setprio(3);
@@ -1228,6 +1237,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
         else if (groups == 2) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
       }
+#endif
       float lim_lam = 0.f;
 #if TREX_STAMPS
       unsigned long long acc_joint = 0;
@@ -1427,6 +1437,18 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
   const float drift = args.w_drift * (head[0] * head[0] + head[1] * head[1]);
   const float energy = args.w_energy * power;
 
+#if TREX_STAMPS
+  // per-wave duration and contact counts of its two envs (scripts/wave_balance.py; buffer >= 3 * 4096 floats)
+  if (DEBUG && args.debug && blockIdx.x < 4096) {
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    const int n1 = __shfl(stat_nc, 32);
+    if (threadIdx.x == 0) {
+      args.debug[4096 + blockIdx.x] = (float)(t_end - wave_t0);
+      args.debug[8192 + blockIdx.x] = (float)(stat_nc + 100 * n1);
+    }
+  }
+#endif
   if (!env_ok) return;
   // ---- failure containment (no reference counterpart): an env whose state stopped being
   // finite is put back on the start pose with zero velocities and reports done = 1 once, with a finite
@@ -1614,13 +1636,51 @@ __global__ void trex_copy_mass_scale_kernel(const float *src, float *dst, int n,
   dst[i] = l < nb ? src[e * nb + l] : 1.0f;
 }
 
+// Wave pairing. A wave solves its two envs one after the other, so its time is the SUM of their row counts
+// and the launch lasts as long as its heaviest wave: sort the envs by the contact count of their previous
+// step (counting sort, 14 bins) and give the k-th lightest env the k-th heaviest as wave partner. The
+// physics of an env does not depend on its partner (tests: permutation equivariance), so any order inside
+// a bin is fine. One workgroup; N / 1024 trips per thread.
+__global__ __launch_bounds__(1024) void trex_pair_kernel(const int32_t *contact_count, int32_t *perm, int n) {
+  __shared__ int hist[16], start[16], fill[16];
+  const int t = threadIdx.x;
+  if (t < 16) { hist[t] = 0; fill[t] = 0; }
+  __syncthreads();
+  for (int i = t; i < n; i += 1024) {
+    const int c = contact_count[i];
+    atomicAdd(&hist[c < 0 ? 0 : (c > 15 ? 15 : c)], 1);
+  }
+  __syncthreads();
+  if (t == 0) {
+    int acc = 0;
+    for (int b = 0; b < 16; b++) { start[b] = acc; acc += hist[b]; }
+  }
+  __syncthreads();
+  const int half = (n + 1) / 2;
+  for (int i = t; i < n; i += 1024) {
+    const int c = contact_count[i];
+    const int b = c < 0 ? 0 : (c > 15 ? 15 : c);
+    const int pos = start[b] + atomicAdd(&fill[b], 1);   // rank by contact count
+    perm[pos < half ? 2 * pos : 2 * (n - 1 - pos) + 1] = i;
+  }
+}
+
 // ---------------------------------------------------------------- host launchers (called by capi.cpp)
 extern "C" {
 
 hipError_t trex_launch_step(const TrexDeviceModel *model, TrexBatchArrays arr, int n, const float *actions,
                             float *obs, float *reward, uint8_t *done, float *penalties, float wd, float we,
                             float wk, float *debug, hipStream_t stream) {
-  KernelArgs a{model, arr, n, actions, obs, reward, done, penalties, nullptr, wd, we, wk, debug};
+  // diagnostics launches keep env 0 and 1 in workgroup 0
+#if TREX_STAMPS
+  // diagnostic build: TREX_DEBUG_PAIR=1 keeps the pairing in debug launches (scripts/wave_balance.py)
+  const bool dbg_pair = getenv("TREX_DEBUG_PAIR") != nullptr;
+  const int32_t *perm = ((debug && !dbg_pair) || n < 4) ? nullptr : arr.pair_perm;
+#else
+  const int32_t *perm = (debug || n < 4) ? nullptr : arr.pair_perm;
+#endif
+  if (perm) hipLaunchKernelGGL(trex_pair_kernel, dim3(1), dim3(1024), 0, stream, arr.contact_count, arr.pair_perm, n);
+  KernelArgs a{model, arr, n, actions, obs, reward, done, penalties, nullptr, perm, wd, we, wk, debug};
   if (debug) hipLaunchKernelGGL((trex_step_kernel<false, true>), dim3((n + 1) / 2), dim3(64), 0, stream, a);
   else hipLaunchKernelGGL((trex_step_kernel<false, false>), dim3((n + 1) / 2), dim3(64), 0, stream, a);
   return hipGetLastError();
@@ -1628,7 +1688,7 @@ hipError_t trex_launch_step(const TrexDeviceModel *model, TrexBatchArrays arr, i
 
 hipError_t trex_launch_reset(const TrexDeviceModel *model, TrexBatchArrays arr, int n, const uint8_t *mask,
                              float *obs, float wd, float we, float wk, float *debug, hipStream_t stream) {
-  KernelArgs a{model, arr, n, nullptr, obs, nullptr, nullptr, nullptr, mask, wd, we, wk, debug};
+  KernelArgs a{model, arr, n, nullptr, obs, nullptr, nullptr, nullptr, mask, nullptr, wd, we, wk, debug};
   hipLaunchKernelGGL((trex_step_kernel<true, false>), dim3((n + 1) / 2), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
@@ -1640,13 +1700,13 @@ hipError_t trex_launch_pack_state(const TrexDeviceModel *model, TrexBatchArrays 
 }
 
 hipError_t trex_launch_head(const TrexDeviceModel *model, TrexBatchArrays arr, int n, float *out, hipStream_t stream) {
-  KernelArgs a{model, arr, n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, nullptr};
+  KernelArgs a{model, arr, n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, nullptr};
   hipLaunchKernelGGL(trex_head_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a, out);
   return hipGetLastError();
 }
 
 hipError_t trex_launch_link_transforms(const TrexDeviceModel *model, TrexBatchArrays arr, int n, float *out, hipStream_t stream) {
-  KernelArgs a{model, arr, n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, nullptr};
+  KernelArgs a{model, arr, n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, nullptr};
   hipLaunchKernelGGL(trex_link_transforms_kernel, dim3(n), dim3(64), 0, stream, a, out);
   return hipGetLastError();
 }

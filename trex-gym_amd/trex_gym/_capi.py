@@ -93,8 +93,15 @@ def check(code):
 
 
 def _ptr(t):
-    """torch tensor / None -> void* (device pointer)."""
-    return None if t is None else C.c_void_p(t.data_ptr())
+    """torch tensor / None -> void* (device pointer). A host tensor here would make the kernel fault the
+    GPU, so it is refused."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise TrexError(-2, "expected a tensor in device memory, got one on %s" % t.device)
+    if not t.is_contiguous():
+        raise TrexError(-2, "expected a contiguous tensor")
+    return C.c_void_p(t.data_ptr())
 
 
 def default_urdf_path():
