@@ -204,6 +204,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "trex_step_kernel<false, false>", "kernel_ms": kernel_ms,
+                         "kernel_ms_covers": "one step launch = trex_pair_kernel (about 7 us: wave pairing by contact "
+                                             "count) + trex_step_kernel<false, false>, bracketed by HIP events",
                          "alg_bytes_per_launch": alg,
                          "note": "latency/VALU-bound by construction (serial PGS); HBM fraction reported as "
                                  "BASELINE asks, see DESIGN.md for the instruction-issue roofline"},

@@ -274,6 +274,35 @@ def test_full_envs_are_independent_and_deterministic(full):
     assert o1.std(0).max() > 0                                 # envs really differ
 
 
+def test_wave_pairing_and_contact_budget(full):
+    """The launch pairs envs by their previous contact count (lightest with heaviest); an env's results
+    must not depend on its history-dependent partner. And the contact budget: never more than 13 points."""
+    v, lo, hi = full
+    g = torch.Generator(device=DEV).manual_seed(7)
+    v.reset_tensor()
+    for t in range(120):   # land: contact counts from 0 to the budget
+        obs, rew, _ = v.step_tensor((lo + (hi - lo) * torch.rand(N_FULL, 25, device=DEV, generator=g)).contiguous())
+    cnt = torch.zeros(N_FULL, dtype=torch.int32, device=DEV)
+    v.batch.contact_stats(cnt, None)
+    assert int(cnt.max()) <= 13 and int(cnt.max()) >= 8 and int(cnt.min()) == 0
+    st = v.get_state()
+    a = (lo + (hi - lo) * torch.rand(N_FULL, 25, device=DEV, generator=g)).contiguous()
+    o1, r1, _ = v.step_tensor(a)
+    o1, r1, s1 = o1.clone(), r1.clone(), v.get_state()
+    # same states, but the stored contact counts (hence the pairing) come from a different history
+    v.reset_tensor()
+    v.step_tensor(a)
+    v.set_state(st)
+    o2, r2, _ = v.step_tensor(a)
+    assert (o1 == o2).all() and (r1 == r2).all() and (s1 == v.get_state()).all()
+
+
+def test_host_tensors_are_refused(full, capi):
+    v, lo, hi = full
+    with pytest.raises(capi.TrexError):
+        v.batch.step(torch.zeros(N_FULL, 25), v.obs, v.rew, v.done)   # host memory: would fault the GPU
+
+
 def test_full_clipping_equals_clipped_actions(full):
     v, lo, hi = full
     g = torch.Generator(device=DEV).manual_seed(2)
