@@ -43,6 +43,18 @@ def main():
         sel = (tot >= lo_) & (tot <= hi_)
         if sel.any():
             print("  waves with %2d..%2d contacts: %4d  cycles mean %.3g  max %.3g" % (lo_, hi_, sel.sum(), cyc[sel].mean(), cyc[sel].max()))
+    if not os.environ.get("TREX_DEBUG_PAIR"):   # wave w = envs 2w, 2w+1: what else makes a wave slow?
+        st = torch.zeros(n, b.state_width, device=dev)
+        b.get_state(st)
+        z = st[:, 2].cpu().numpy().reshape(-1, 2).min(1)
+        sp = st[:, 38:63].abs().max(1).values.cpu().numpy().reshape(-1, 2).max(1)
+        zero = tot == 0
+        print("zero-contact waves: corr(cycles, min base z) %.2f  corr(cycles, max |qd|) %.2f" % (
+            np.corrcoef(cyc[zero], z[zero])[0, 1], np.corrcoef(cyc[zero], sp[zero])[0, 1]))
+        for zl, zh in ((0, 1.0), (1.0, 2.0), (2.0, 3.0), (3.0, 9.0)):
+            sel = zero & (z >= zl) & (z < zh)
+            if sel.any():
+                print("  zero-contact waves with min base z in [%.1f, %.1f): %4d  cycles mean %.3g max %.3g" % (zl, zh, sel.sum(), cyc[sel].mean(), cyc[sel].max()))
     k = np.argsort(-cyc)[:8]
     print("slowest waves (cycles, contacts env a, env b):", [(int(cyc[i]), int(n0[i]), int(n1[i])) for i in k])
 

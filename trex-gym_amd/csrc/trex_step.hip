@@ -43,6 +43,9 @@
 #ifndef TREX_STAMPS
 #define TREX_STAMPS 0
 #endif
+#ifndef TREX_PRIO_MODE
+#define TREX_PRIO_MODE 2   // 0 none, 1 per-env priority during its sweeps, 2 per-wave priority from contact generation on
+#endif
 // Diagnostic build only (make stamps): s_memtime at phase boundaries of workgroup 0, written to the
 // debug buffer at [3000 + 16*substep + phase] as cycle deltas. Never compiled into the product library.
 #if TREX_STAMPS
@@ -967,6 +970,15 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
 
     STAMP2(4);
     STAMP(8);
+#if TREX_PRIO_MODE == 2
+    {   // wave-level priority for the rest of the substep: total contact rows of the two envs
+      const int tot = __builtin_amdgcn_readlane(nc, 0) + __builtin_amdgcn_readlane(nc, 32);
+      if (tot >= 12) __builtin_amdgcn_s_setprio(3);
+      else if (tot >= 8) __builtin_amdgcn_s_setprio(2);
+      else if (tot >= 4) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
+#endif
     // ---- constraint solve: projected Gauss-Seidel in DELASSUS (residual) form, one env at a time on all
     // 64 lanes. Rows of an env: 25 motor rows (joint j, with the joint's limit row riding on the same lane)
     // and 3 rows per contact point (normal z, friction x, friction y). Each row s lives on ONE lane and keeps
@@ -1229,7 +1241,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       STAMP(10);
       // The launch lasts as long as its heaviest wave: let a wave with many rows win the issue arbitration
       // against its lighter SIMD partner.
-#ifndef TREX_NO_PRIO
+#if TREX_PRIO_MODE == 1
       {
         const int groups = (ncE + 3) >> 2;
         if (groups >= 4) __builtin_amdgcn_s_setprio(3);
@@ -1303,7 +1315,9 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
           }
         }
       }
+#if TREX_PRIO_MODE == 1
       __builtin_amdgcn_s_setprio(0);
+#endif
       STAMP(12);
 #if TREX_STAMPS
       if (DEBUG && args.debug && blockIdx.x == 0 && threadIdx.x == 0) {
