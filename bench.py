@@ -134,7 +134,7 @@ def main():
 
     events = []
     force_gather = under_launcher and world == 1 and bool(os.environ.get("TREX_BENCH_FORCE_GATHER"))
-    gather_buf = torch.empty_like(env.obs) if force_gather else None
+    pipe = (sharding.PipelinedGather(env.num_envs, env.obs.shape[1], 1, env.obs.dtype, dev) if force_gather else None)
 
     def run(n_steps, t_base, timed=False):
         for t in range(n_steps):
@@ -146,9 +146,9 @@ def main():
                 e1.record()
                 events.append((e0, e1))
             if world > 1:
-                env.all_gather_obs()
+                env.all_gather_obs_pipelined()   # overlaps the next step; consumer sees obs one step late
             elif force_gather:   # one-GPU rehearsal of the collective call itself (RCCL, world of 1)
-                dist.all_gather_into_tensor(gather_buf, env.obs)
+                pipe.push(env.obs)
             if (t_base + t + 1) % EPISODE_STEPS == 0:
                 env.reset_tensor()
 
@@ -196,7 +196,7 @@ def main():
                                    "vertices), uniform random actions keyed by global env id, 5 substeps x 60 "
                                    "PGS iterations per step, episode limit %d steps%s"
                                    % (args.envs_per_gpu, world, EPISODE_STEPS,
-                                      ", obs all-gather over RCCL each step" if world > 1 else ""),
+                                      ", obs all-gather over RCCL each step, overlapped with the next step (gathered rows are one step old)" if world > 1 else ""),
                        "envs_global": n_global, "parallelism": "env-sharded dp%d" % world,
                        **({"domain_randomisation": "mass_scale U(0.8,1.2) per body, friction U(0.5,1.25), seed 1"}
                           if args.domain_rand else {}),

@@ -97,3 +97,36 @@ def test_two_rank_gloo_gather_equals_single_process(n_global):
     assert got.shape == want.shape
     assert torch.equal(got, want)
     assert not torch.equal(want[0], want[1])   # different global ids -> different actions -> rows
+
+
+def _pipe_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "trex-gym_amd"))
+    from trex_gym import sharding
+    pipe = sharding.PipelinedGather(3, 5, world, torch.float32, "cpu")
+    got = []
+    for t in range(4):
+        local = torch.full((3, 5), float(10 * t + rank))
+        prev = pipe.push(local)
+        local.fill_(-1.0)    # the caller may overwrite its rows at once (they were staged)
+        got.append(None if prev is None else prev.clone())
+    got.append(pipe.flush().clone())
+    if rank == 1:
+        ret["got"] = got
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_gather_returns_the_previous_step(tmp_path):
+    """The overlapped all-gather of bench.py --gpus N: call t returns the rows of call t-1, from every rank."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_pipe_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    got = ret["got"]
+    assert got[0] is None
+    for t in range(1, 5):
+        want = torch.cat([torch.full((3, 5), float(10 * (t - 1) + r)) for r in range(2)])
+        assert torch.equal(got[t], want), t

@@ -62,3 +62,42 @@ def all_gather_rows(local, global_rows, world_size, group=None, out=None):
         lo, hi = shard_range(global_rows, r, world_size)
         pieces.append(buf[r * per: r * per + (hi - lo)])
     return torch.cat(pieces, 0)
+
+
+class PipelinedGather:
+    """All-gather of the per-rank observation rows that overlaps the NEXT env step: the rows are copied
+    to one of two staging blocks on the compute stream (stream-ordered after the step that produced them),
+    the collective is launched asynchronously on the communicator's stream, and the call returns the
+    block gathered ONE call earlier - complete by then, or made so by waiting on its work handle. A
+    centralised consumer therefore sees observations one step late, and no step waits for xGMI.
+    Equal shards only (the bench / trainer case); ragged shards go through all_gather_rows."""
+
+    def __init__(self, rows_local, cols, world_size, dtype, device, group=None):
+        self.world, self.group = int(world_size), group
+        self.stage = [torch.empty(rows_local, cols, dtype=dtype, device=device) for _ in range(2)]
+        self.out = [torch.empty(rows_local * self.world, cols, dtype=dtype, device=device) for _ in range(2)]
+        self.work = [None, None]
+        self.k = 0
+
+    def push(self, local):
+        """Launch the gather of `local`; returns the previous call's gathered rows (None on the first)."""
+        k = self.k
+        if self.work[k] is not None:     # the collective that last read stage[k] / wrote out[k]
+            self.work[k].wait()
+        self.stage[k].copy_(local)
+        self.work[k] = dist.all_gather_into_tensor(self.out[k], self.stage[k], group=self.group, async_op=True)
+        prev = 1 - k
+        self.k = prev
+        if self.work[prev] is None:
+            return None
+        self.work[prev].wait()
+        return self.out[prev]
+
+    def flush(self):
+        """Wait for everything in flight; returns the most recent gathered rows."""
+        last = None
+        for k in (self.k, 1 - self.k):
+            if self.work[k] is not None:
+                self.work[k].wait()
+                last = self.out[k]
+        return last

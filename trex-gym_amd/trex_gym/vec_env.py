@@ -64,6 +64,7 @@ class TrexVecEnv:
         self.max_episode_steps = max_episode_steps
         self._actions = None
         self._gather_buf = None
+        self._pipe = None
 
     # ---- tensor-native API (stays on device, stream-ordered, no host sync)
     def reset_tensor(self, mask=None):
@@ -102,6 +103,19 @@ class TrexVecEnv:
         self._gather_buf = sharding.all_gather_rows(obs, self.global_num_envs, self.world_size,
                                                     self.process_group, out=self._gather_buf)
         return self._gather_buf
+
+    def all_gather_obs_pipelined(self, obs=None):
+        """Like all_gather_obs, but the collective overlaps the next step: returns the rows gathered by the
+        PREVIOUS call (None on the first). See sharding.PipelinedGather."""
+        obs = self.obs if obs is None else obs
+        if self.world_size == 1:
+            return obs
+        if self._pipe is None:
+            if self.global_num_envs != self.num_envs * self.world_size:
+                raise ValueError("pipelined gather needs equal shards")
+            self._pipe = sharding.PipelinedGather(self.num_envs, obs.shape[1], self.world_size, obs.dtype,
+                                                  self.device, self.process_group)
+        return self._pipe.push(obs)
 
     # ---- baselines VecEnv API (host numpy in/out)
     def reset(self):
