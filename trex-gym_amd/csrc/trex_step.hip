@@ -1181,34 +1181,35 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       else if (tid >= 32) row0 = CROW0 + (tid - 32);
       else row0 = CROW0 + 32 + (tid == 0 ? 0 : tid - 25);   // lanes 0, 26..31 -> contact rows 32..38
       int ca0[MAXD];
-      float u0[MAXD], r00[6], inv0, y, lam = 0.f;
+      float u0[MAXD], r00[6], zc0[MAXD], z00[6], inv0, y, lam = 0.f;
       {
         const float *c = reinterpret_cast<const float *>(W.u.rows.col[row0]);
         const float *o = W.u.rows.own[row0];
 #pragma unroll
-        for (int d = 0; d < MAXD; d++) { ca0[d] = __float_as_int(c[d]); u0[d] = o[d]; r00[d] = o[6 + d]; }
+        for (int d = 0; d < MAXD; d++) { ca0[d] = __float_as_int(c[d]); zc0[d] = c[6 + d]; z00[d] = c[12 + d]; u0[d] = o[d]; r00[d] = o[6 + d]; }
         inv0 = o[12]; y = o[13];
       }
-      auto read_col = [&](int row, int *car, float *zcr, float *z0r) {
-        const float4 *c4 = W.u.rows.col[row];
-        const float4 q0 = c4[0], q1 = c4[1], q2 = c4[2], q3 = c4[3], q4 = c4[4];
-        car[0] = __float_as_int(q0.x); car[1] = __float_as_int(q0.y); car[2] = __float_as_int(q0.z); car[3] = __float_as_int(q0.w);
-        car[4] = __float_as_int(q1.x); car[5] = __float_as_int(q1.y);
-        zcr[0] = q1.z; zcr[1] = q1.w; zcr[2] = q2.x; zcr[3] = q2.y; zcr[4] = q2.z; zcr[5] = q2.w;
-        z0r[0] = q3.x; z0r[1] = q3.y; z0r[2] = q3.z; z0r[3] = q3.w; z0r[4] = q4.x; z0r[5] = q4.y;
-      };
-      // -- motor columns -> LDS (unused chain slots hold u = zc = 0, so a -1 == -1 match adds nothing)
-#pragma unroll 5
-      for (int k = 0; k < NJMAX; k++) {
-        int car[MAXD];
-        float zcr[MAXD], z0r[6];
-        read_col(e * NJMAX + k, car, zcr, z0r);
-        float a0_ = dot6(r00, z0r);
+      // B entries of this lane's row against column r: the column's descriptor (ca, zc, z0: 18 words) sits in
+      // the registers of the lane that owns row r and is broadcast with v_readlane into SGPRs - no LDS round
+      // trip per column. Unused chain slots hold u = zc = 0, so a -1 == -1 match adds nothing.
+      auto bcast_i = [&](int v, int L) { return __builtin_amdgcn_readlane(v, L); };
+      auto bcast_f = [&](float v, int L) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), L)); };
+      // -- motor columns -> registers (and LDS for the dynamic limit rows); column j is row lane j
+      float Bm[NJMAX];
 #pragma unroll
-        for (int d = 0; d < MAXD; d++) a0_ += (ca0[d] == car[d]) ? u0[d] * zcr[d] : 0.f;
-        W.jcol[k][tid] = -inv0 * a0_;
+      for (int j = 1; j <= NJMAX; j++) {
+        float a0_ = 0.f;
+#pragma unroll
+        for (int d = 0; d < 6; d++) a0_ = __builtin_fmaf(r00[d], bcast_f(z00[d], j), a0_);
+#pragma unroll
+        for (int d = 0; d < MAXD; d++) {
+          const float m = (ca0[d] == bcast_i(ca0[d], j)) ? u0[d] : 0.f;
+          a0_ = __builtin_fmaf(m, bcast_f(zc0[d], j), a0_);
+        }
+        Bm[j - 1] = -inv0 * a0_;
+        W.jcol[j - 1][tid] = Bm[j - 1];
       }
-      // -- contact columns -> registers
+      // -- contact columns -> registers; column k is row lane krow_lane(k), the chain is shared by a point's rows
       float Bc[3 * MAXC];
 #pragma unroll
       for (int c = 0; c < MAXC; c++) {
@@ -1217,27 +1218,21 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
         if (c < ncE) {
           float m0[MAXD];
 #pragma unroll
+          for (int d = 0; d < MAXD; d++) m0[d] = (ca0[d] == bcast_i(ca0[d], krow_lane(3 * c))) ? u0[d] : 0.f;
+#pragma unroll
           for (int a = 0; a < 3; a++) {
             const int k = 3 * c + a;
-            int car[MAXD];
-            float zcr[MAXD], z0r[6];
-            read_col(CROW0 + k, car, zcr, z0r);
-            if (a == 0) {
+            const int L = krow_lane(k);
+            float a0_ = 0.f;
 #pragma unroll
-              for (int d = 0; d < MAXD; d++) m0[d] = (ca0[d] == car[d]) ? u0[d] : 0.f;
-            }
-            float a0_ = dot6(r00, z0r);
+            for (int d = 0; d < 6; d++) a0_ = __builtin_fmaf(r00[d], bcast_f(z00[d], L), a0_);
 #pragma unroll
-            for (int d = 0; d < MAXD; d++) a0_ += m0[d] * zcr[d];
+            for (int d = 0; d < MAXD; d++) a0_ = __builtin_fmaf(m0[d], bcast_f(zc0[d], L), a0_);
             Bc[k] = -inv0 * a0_;
           }
         }
       }
       __syncthreads();
-      // motor columns back into registers for the sweeps (the LDS copy serves the dynamic limit rows)
-      float Bm[NJMAX];
-#pragma unroll
-      for (int j = 0; j < NJMAX; j++) Bm[j] = W.jcol[j][tid];
       STAMP(10);
       // The launch lasts as long as its heaviest wave: let a wave with many rows win the issue arbitration
       // against its lighter SIMD partner.
