@@ -1042,107 +1042,97 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       // -- contact rows of env e: walk (both teams walk, team e stages) - skipped for an airborne env
       __syncthreads();
       if (ncE > 0) {
-        float c_rhs[3] = {0.f, 0.f, 0.f}, c_inv[3] = {0.f, 0.f, 0.f};
-        float c_z0[3][6], c_zc[3][MAXD], c_u[3][MAXD], c_r0[3][6];
-        int c_anc[MAXD];
-        {
-          const bool has = lane < nc;
-          // updated body velocities (after the unconstrained step) for the row right-hand sides
-          float nvel[6];
-          body_velocities(nw, nv, nqd, nvel);
-          float vb[6];
-    #pragma unroll
-          for (int k = 0; k < 6; k++) vb[k] = tshfl(nvel[k], cbody);
-          float p[3][6], diag[3] = {0.f, 0.f, 0.f};
-          const float dirs[3][3] = {{0.f, 0.f, 1.f}, {1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}};
-          float po[3], xrel[3];   // po: the point the forces p[a] refer to (body origin first, then up the chain)
-    #pragma unroll
-          for (int k = 0; k < 3; k++) { po[k] = tshfl(r[k], cbody); xrel[k] = cx[k] - po[k]; }
-    #pragma unroll
-          for (int a = 0; a < 3; a++) {
-            float xd[3];
-            cross3(xrel, dirs[a], xd);
-    #pragma unroll
-            for (int k = 0; k < 3; k++) { p[a][k] = -xd[k]; p[a][3 + k] = -dirs[a][k]; }
-          }
-    #pragma unroll
-          for (int d = MAXD; d >= 1; d--) {
-            c_anc[d - 1] = -1;
-    #pragma unroll
-            for (int a = 0; a < 3; a++) { c_zc[a][d - 1] = 0.f; c_u[a][d - 1] = 0.f; }
-            if (d <= maxdepth) {
-              const int ab = tshfl(anc[d - 1], cbody);
-              c_anc[d - 1] = has ? ab : -1;
-              const int src = ab < 0 ? 0 : ab;
-              float aa[3], Uda[6], ra[3];
-    #pragma unroll
-              for (int k = 0; k < 3; k++) { aa[k] = tshfl(S[k], src); ra[k] = tshfl(r[k], src); }
-    #pragma unroll
-              for (int k = 0; k < 6; k++) Uda[k] = tshfl(Ud[k], src);
-              const float invDa = tshfl(invD, src);
-              if (has && ab >= 0) {
-                float dd[3];
-    #pragma unroll
-                for (int k = 0; k < 3; k++) { dd[k] = po[k] - ra[k]; po[k] = ra[k]; }
-    #pragma unroll
-                for (int a = 0; a < 3; a++) {
-                  float dxf[3];
-                  cross3(dd, p[a] + 3, dxf);
-    #pragma unroll
-                  for (int k = 0; k < 3; k++) p[a][k] += dxf[k];
-                  const float ua = -dot3(aa, p[a]);
-                  c_u[a][d - 1] = ua;
-                  c_zc[a][d - 1] = ua * invDa;
-                  diag[a] += ua * ua * invDa;
-    #pragma unroll
-                  for (int k = 0; k < 6; k++) p[a][k] += Uda[k] * ua;
-                }
+        // Every number of a row descriptor goes to the LDS stage the moment it is known (team e's point
+        // lanes write, the others only walk): nothing but the three running forces p[a] is carried.
+        const bool has = lane < nc;
+        const bool st = (team == e) && lane < MAXC;
+        float *colf = reinterpret_cast<float *>(W.u.rows.col[CROW0 + 3 * (st ? lane : 0)]);   // 20 words per row
+        float *ownf = W.u.rows.own[CROW0 + 3 * (st ? lane : 0)];                               // 15 words per row
+        // updated body velocities (after the unconstrained step) for the row right-hand sides
+        float nvel[6];
+        body_velocities(nw, nv, nqd, nvel);
+        float vb[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) vb[k] = tshfl(nvel[k], cbody);
+        float p[3][6], diag[3] = {0.f, 0.f, 0.f};
+        const float dirs[3][3] = {{0.f, 0.f, 1.f}, {1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}};
+        float po[3], xrel[3];   // po: the point the forces p[a] refer to (body origin first, then up the chain)
+#pragma unroll
+        for (int k = 0; k < 3; k++) { po[k] = tshfl(r[k], cbody); xrel[k] = cx[k] - po[k]; }
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          float xd[3];
+          cross3(xrel, dirs[a], xd);
+#pragma unroll
+          for (int k = 0; k < 3; k++) { p[a][k] = -xd[k]; p[a][3 + k] = -dirs[a][k]; }
+        }
+#pragma unroll
+        for (int d = MAXD; d >= 1; d--) {
+          int ca = -1;
+          float ua[3] = {0.f, 0.f, 0.f}, zc[3] = {0.f, 0.f, 0.f};
+          if (d <= maxdepth) {
+            const int ab = tshfl(anc[d - 1], cbody);
+            ca = has ? ab : -1;
+            const int src = ab < 0 ? 0 : ab;
+            float aa[3], Uda[6], ra[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { aa[k] = tshfl(S[k], src); ra[k] = tshfl(r[k], src); }
+#pragma unroll
+            for (int k = 0; k < 6; k++) Uda[k] = tshfl(Ud[k], src);
+            const float invDa = tshfl(invD, src);
+            if (has && ab >= 0) {
+              float dd[3];
+#pragma unroll
+              for (int k = 0; k < 3; k++) { dd[k] = po[k] - ra[k]; po[k] = ra[k]; }
+#pragma unroll
+              for (int a = 0; a < 3; a++) {
+                float dxf[3];
+                cross3(dd, p[a] + 3, dxf);
+#pragma unroll
+                for (int k = 0; k < 3; k++) p[a][k] += dxf[k];
+                ua[a] = -dot3(aa, p[a]);
+                zc[a] = ua[a] * invDa;
+                diag[a] += ua[a] * ua[a] * invDa;
+#pragma unroll
+                for (int k = 0; k < 6; k++) p[a][k] += Uda[k] * ua[a];
               }
             }
           }
-          float pvel[3], wxx[3];
-          cross3(vb, xrel, wxx);   // body velocity is about the body origin
-          float I0l[21];
-  #pragma unroll
-          for (int k = 0; k < 21; k++) I0l[k] = W.i0inv[team][k];
-    #pragma unroll
-          for (int k = 0; k < 3; k++) pvel[k] = vb[3 + k] + wxx[k];
-    #pragma unroll
-          for (int a = 0; a < 3; a++) {
-            float rhs0[6], dxf[3];
-            cross3(po, p[a] + 3, dxf);   // on to the base origin O
-    #pragma unroll
-            for (int k = 0; k < 3; k++) p[a][k] += dxf[k];
-    #pragma unroll
-            for (int k = 0; k < 6; k++) { rhs0[k] = -p[a][k]; c_r0[a][k] = rhs0[k]; }
-            inv21_mul(I0l, rhs0, c_z0[a]);
-            diag[a] += dot6(rhs0, c_z0[a]);
-            c_inv[a] = has ? 1.0f / diag[a] : 0.f;
-            float tv = 0.f;
-            if (a == 0) tv = (cdist > 0.f) ? -cdist * inv_dt : -cdist * cerp * inv_dt;
-            c_rhs[a] = (tv - dot3(dirs[a], pvel)) * c_inv[a];
+          if (st) {
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+              colf[20 * a + d - 1] = __int_as_float(ca);
+              colf[20 * a + 6 + d - 1] = zc[a];
+              ownf[15 * a + d - 1] = ua[a];
+            }
           }
         }
-        if (team == e) {
-          RowStage &S_ = W.u.rows;
-          if (lane < MAXC) {
-            const bool has = lane < nc;
-  #pragma unroll
-            for (int a = 0; a < 3; a++) {
-              const int row = CROW0 + 3 * lane + a;
-              int ca[MAXD];
-  #pragma unroll
-              for (int d = 0; d < MAXD; d++) ca[d] = has ? c_anc[d] : -1;
-              S_.col[row][0] = make_float4(__int_as_float(ca[0]), __int_as_float(ca[1]), __int_as_float(ca[2]), __int_as_float(ca[3]));
-              S_.col[row][1] = make_float4(__int_as_float(ca[4]), __int_as_float(ca[5]), has ? c_zc[a][0] : 0.f, has ? c_zc[a][1] : 0.f);
-              S_.col[row][2] = make_float4(has ? c_zc[a][2] : 0.f, has ? c_zc[a][3] : 0.f, has ? c_zc[a][4] : 0.f, has ? c_zc[a][5] : 0.f);
-              S_.col[row][3] = make_float4(has ? c_z0[a][0] : 0.f, has ? c_z0[a][1] : 0.f, has ? c_z0[a][2] : 0.f, has ? c_z0[a][3] : 0.f);
-              S_.col[row][4] = make_float4(has ? c_z0[a][4] : 0.f, has ? c_z0[a][5] : 0.f, 0.f, 0.f);
-              float *o = S_.own[row];
-  #pragma unroll
-              for (int d = 0; d < MAXD; d++) { o[d] = has ? c_u[a][d] : 0.f; o[6 + d] = has ? c_r0[a][d] : 0.f; }
-              o[12] = has ? c_inv[a] : 0.f; o[13] = has ? c_rhs[a] : 0.f;
-            }
+        float pvel[3], wxx[3];
+        cross3(vb, xrel, wxx);   // body velocity is about the body origin
+        float I0l[21];
+#pragma unroll
+        for (int k = 0; k < 21; k++) I0l[k] = W.i0inv[team][k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) pvel[k] = vb[3 + k] + wxx[k];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          float rhs0[6], z0[6], dxf[3];
+          cross3(po, p[a] + 3, dxf);   // on to the base origin O
+#pragma unroll
+          for (int k = 0; k < 3; k++) p[a][k] += dxf[k];
+#pragma unroll
+          for (int k = 0; k < 6; k++) rhs0[k] = -p[a][k];
+          inv21_mul(I0l, rhs0, z0);
+          diag[a] += dot6(rhs0, z0);
+          const float inv = has ? 1.0f / diag[a] : 0.f;
+          float tv = 0.f;
+          if (a == 0) tv = (cdist > 0.f) ? -cdist * inv_dt : -cdist * cerp * inv_dt;
+          const float rhs = (tv - dot3(dirs[a], pvel)) * inv;
+          if (st) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) { colf[20 * a + 12 + k] = has ? z0[k] : 0.f; ownf[15 * a + 6 + k] = has ? rhs0[k] : 0.f; }
+            colf[20 * a + 18] = 0.f; colf[20 * a + 19] = 0.f;
+            ownf[15 * a + 12] = inv; ownf[15 * a + 13] = has ? rhs : 0.f; ownf[15 * a + 14] = 0.f;
           }
         }
       } else if (team == e && lane < MAXC) {
