@@ -80,7 +80,9 @@ int trex_model_fit_hull_primitives(const TrexModel *model, int group, double max
 /* engine parameters: "dt" "substeps" "iterations" "gravity" "motor_kp" "motor_kd" "motor_max_force"
  * "floor_z" "friction" "erp" "contact_erp" "contact_margin" "link_damping"
  * "max_coordinate_velocity" "max_contacts"  (setTimeStep / setPhysicsEngineParameter / setGravity,
- * trex_env.py:115-117; motor gains trex_robot.py:260,401,421). */
+ * trex_env.py:115-117; motor gains trex_robot.py:260,401,421). "max_contacts" is the contact-point budget
+ * per env: default and upper limit 13 (25 motor rows + 3 x 13 contact rows = the 64 lanes of a wavefront;
+ * larger values are clamped by the kernel). */
 int trex_model_set_param(TrexModel *model, const char *name, double value);
 int trex_model_get_param(const TrexModel *model, const char *name, double *value);
 
