@@ -824,7 +824,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       const bool small = near && nverts <= SMALL_HULL;
       if (wave_any(small)) {
         float bs = -3.0e38f;
-        constexpr int UN = 8;   // 8 independent 16-B loads in flight per lane (128 contiguous bytes)
+        constexpr int UN = 16;   // 16 independent 16-B loads in flight per lane (256 contiguous bytes)
         for (int i0 = 0; wave_any(small && i0 < nverts); i0 += UN) {
           float4 h[UN];
 #pragma unroll
@@ -835,15 +835,19 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
 #pragma unroll
           for (int u = 0; u < UN; u++) {
             const int i = i0 + u;
-            const float hv[3] = {h[u].x, h[u].y, h[u].z};
-            float w[3];
-            matvec3(R, hv, w);
+            // only the height decides; the winner's position is formed once, after the scan.
             // h.w = support radius (0 for a hull vertex): the contact point is the sphere's lowest point
-            const float dd = pos[2] + r[2] + w[2] - h[u].w - floor_z;
-            if (small && i < nverts && dd < margin && -dd > bs) {
-              bs = -dd; a_v = hull_v0 + i; a_x[0] = r[0] + w[0]; a_x[1] = r[1] + w[1]; a_x[2] = r[2] + w[2] - h[u].w; a_d = dd;
-            }
+            const float wz = R[6] * h[u].x + R[7] * h[u].y + R[8] * h[u].z;
+            const float dd = pos[2] + r[2] + wz - h[u].w - floor_z;
+            if (small && i < nverts && dd < margin && -dd > bs) { bs = -dd; a_v = hull_v0 + i; a_d = dd; }
           }
+        }
+        if (small && a_v >= 0) {
+          const float4 hw = args.arr.hull[a_v];
+          const float hv[3] = {hw.x, hw.y, hw.z};
+          float w[3];
+          matvec3(R, hv, w);
+          a_x[0] = r[0] + w[0]; a_x[1] = r[1] + w[1]; a_x[2] = r[2] + w[2] - hw.w;
         }
         active_mask |= tballot(small && a_v >= 0);
       }
