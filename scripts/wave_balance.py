@@ -26,7 +26,7 @@ def main():
     for t in range(int(sys.argv[1]) if len(sys.argv) > 1 else 230):
         a = sharding.synthetic_actions(ids, t, lo, hi, device=dev)
         b.step(a, obs, rew, done)
-    dbg = torch.zeros(3 * 4096, device=dev)
+    dbg = torch.zeros(6 * 4096, device=dev)
     a = sharding.synthetic_actions(ids, 1000, lo, hi, device=dev)
     b.debug_step(a, obs, dbg)
     torch.cuda.synchronize()
@@ -34,6 +34,12 @@ def main():
     cyc = d[4096:4096 + n // 2]
     code = d[8192:8192 + n // 2].astype(int)
     n0, n1 = code % 100, code // 100
+    cg = d[12288:12288 + n // 2]
+    cg1, cg2 = d[16384:16384 + n // 2], d[20480:20480 + n // 2]
+    print("  of which small-hull scan mean %.3g max %.3g, large-hull scan mean %.3g max %.3g, point selection (K >= 2 re-scans, fast path) mean %.3g max %.3g"
+          % (cg1.mean(), cg1.max(), cg2.mean(), cg2.max(), (cg - cg1 - cg2).mean(), (cg - cg1 - cg2).max()))
+    print("contact generation per wave: mean %.3g  p90 %.3g  max %.3g cycles; corr(wave cycles, contact-generation cycles) %.2f"
+          % (cg.mean(), np.percentile(cg, 90), cg.max(), np.corrcoef(cyc, cg)[0, 1]))
     tot = n0 + n1
     print("pairing in this launch:", "on" if os.environ.get("TREX_DEBUG_PAIR") else "off")
     print("wave cycles: mean %.3g  median %.3g  p90 %.3g  p99 %.3g  max %.3g  (max/mean %.2f)"
@@ -56,7 +62,8 @@ def main():
             if sel.any():
                 print("  zero-contact waves with min base z in [%.1f, %.1f): %4d  cycles mean %.3g max %.3g" % (zl, zh, sel.sum(), cyc[sel].mean(), cyc[sel].max()))
     k = np.argsort(-cyc)[:8]
-    print("slowest waves (cycles, contacts env a, env b):", [(int(cyc[i]), int(n0[i]), int(n1[i])) for i in k])
+    print("slowest waves (cycles, of which contact generation, contacts env a, env b):",
+          [(int(cyc[i]), int(cg[i]), int(n0[i]), int(n1[i])) for i in k])
 
 
 if __name__ == "__main__":

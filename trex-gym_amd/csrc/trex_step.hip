@@ -314,6 +314,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
   __shared__ WaveLds W;
 #if TREX_STAMPS
   const unsigned long long wave_t0 = __builtin_amdgcn_s_memtime();
+  unsigned long long wave_cg = 0, wave_cg1 = 0, wave_cg2 = 0;   // cycles in contact generation: all, small-hull scan, large-hull scan
 #endif
   const int lane = threadIdx.x & (TL - 1);
   const int team = threadIdx.x >> 5;
@@ -797,6 +798,9 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
     }
 
     STAMP(7);
+#if TREX_STAMPS
+    const unsigned long long cg_t0 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- contact generation: hull vertices against z <= floor_z
     // Pass A walks the near bodies once: it finds whether a body has any vertex inside the margin and,
     // in the same sweep, its DEEPEST such vertex (= the first point the selection rule keeps), parked in
@@ -822,10 +826,17 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       constexpr int SMALL_HULL = 96;
       const int nverts = hull_v1 - hull_v0;
       const bool small = near && nverts <= SMALL_HULL;
+      // In-margin vertex sets, kept for the point selection (pass B never sweeps a hull again): a small body's
+      // lane keeps bit i of cm[i / 32] for its vertex i; for the (at most two) large bodies every team lane
+      // keeps bit i for its strided vertex v0 + lane + 32 i.
+      unsigned cm0 = 0u, cm1 = 0u, cm2 = 0u;
+      unsigned imL0 = 0u, imL1 = 0u;
+      int bL0 = -1, bL1 = -1;
       if (wave_any(small)) {
         float bs = -3.0e38f;
         constexpr int UN = 16;   // 16 independent 16-B loads in flight per lane (256 contiguous bytes)
         for (int i0 = 0; wave_any(small && i0 < nverts); i0 += UN) {
+          unsigned bm = 0u;
           float4 h[UN];
 #pragma unroll
           for (int u = 0; u < UN; u++) {
@@ -839,8 +850,14 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
             // h.w = support radius (0 for a hull vertex): the contact point is the sphere's lowest point
             const float wz = R[6] * h[u].x + R[7] * h[u].y + R[8] * h[u].z;
             const float dd = pos[2] + r[2] + wz - h[u].w - floor_z;
-            if (small && i < nverts && dd < margin && -dd > bs) { bs = -dd; a_v = hull_v0 + i; a_d = dd; }
+            const bool in = small && i < nverts && dd < margin;
+            bm |= in ? (1u << u) : 0u;
+            if (in && -dd > bs) { bs = -dd; a_v = hull_v0 + i; a_d = dd; }
           }
+          const unsigned add = bm << (i0 & 16);
+          if ((i0 >> 5) == 0) cm0 |= add;
+          else if ((i0 >> 5) == 1) cm1 |= add;
+          else cm2 |= add;
         }
         if (small && a_v >= 0) {
           const float4 hw = args.arr.hull[a_v];
@@ -851,6 +868,10 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
         }
         active_mask |= tballot(small && a_v >= 0);
       }
+#if TREX_STAMPS
+      const unsigned long long cg_t1 = __builtin_amdgcn_s_memtime();
+      wave_cg1 += cg_t1 - cg_t0;
+#endif
       STAMP2(0);
       // (ii) large hulls (cranium, pelvis+ribcage): the team strides over the vertices together
       unsigned near_mask = tballot(near && !small);
@@ -866,13 +887,36 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
         const int v0 = tshfl(hull_v0, b), v1 = tshfl(hull_v1, b);
         float bs = -3.0e38f, bx[3] = {0.f, 0.f, 0.f};
         int bi = 0x7fffffff;
-        for (int v = v0 + lane; v < v1; v += TL) {
-          const float4 h = args.arr.hull[v];
-          const float hv[3] = {h.x, h.y, h.z};
+        unsigned im = 0u;
+        constexpr int UL = 4;   // 4 coalesced 512-B loads in flight per team
+        for (int it0 = 0; wave_any(valid && v0 + TL * it0 < v1); it0 += UL) {
+          float4 h[UL];
+#pragma unroll
+          for (int u = 0; u < UL; u++) {
+            const int v = v0 + lane + TL * (it0 + u);
+            h[u] = args.arr.hull[(valid && v < v1) ? v : v0];
+          }
+#pragma unroll
+          for (int u = 0; u < UL; u++) {
+            const int v = v0 + lane + TL * (it0 + u);
+            const float wz = Rb[6] * h[u].x + Rb[7] * h[u].y + Rb[8] * h[u].z;   // the height decides
+            const float dd = pos[2] + rb[2] + wz - h[u].w - floor_z;
+            if (valid && v < v1 && dd < margin) {
+              im |= (it0 + u < 32) ? (1u << (it0 + u)) : 0u;
+              if (-dd > bs) { bs = -dd; bi = v; }
+            }
+          }
+        }
+        if (bi != 0x7fffffff) {   // position of this lane's deepest vertex, once
+          const float4 hw = args.arr.hull[bi];
+          const float hv[3] = {hw.x, hw.y, hw.z};
           float w[3];
           matvec3(Rb, hv, w);
-          const float dd = pos[2] + rb[2] + w[2] - h.w - floor_z;
-          if (dd < margin && -dd > bs) { bs = -dd; bi = v; bx[0] = rb[0] + w[0]; bx[1] = rb[1] + w[1]; bx[2] = rb[2] + w[2] - h.w; }
+          bx[0] = rb[0] + w[0]; bx[1] = rb[1] + w[1]; bx[2] = rb[2] + w[2] - hw.w;
+        }
+        if (valid) {
+          if (bL0 < 0) { bL0 = b; imL0 = im; }
+          else if (bL1 < 0) { bL1 = b; imL1 = im; }
         }
         const int mine = bi;
         targmax(bs, bi);
@@ -883,6 +927,9 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
           if (lane == b) { a_x[0] = wx; a_x[1] = wy; a_x[2] = wz; a_d = -bs; a_v = bi; }
         }
       }
+#if TREX_STAMPS
+      wave_cg2 += __builtin_amdgcn_s_memtime() - cg_t1;
+#endif
       STAMP2(1);
       const int n_active = __popc(active_mask);
       int K = n_active > 0 ? maxc / n_active : 0;
@@ -919,6 +966,20 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
 #pragma unroll
           for (int c = 0; c < 3; c++) rb[c] = tshfl(r[c], b);
           const int v0 = tshfl(hull_v0, b), v1 = tshfl(hull_v1, b);
+          // this lane's candidates of body b: bit i <-> vertex v0 + lane + 32 i (in the margin during pass A)
+          unsigned im;
+          const bool masked = (v1 - v0) <= 1024 && ((v1 - v0) <= SMALL_HULL || b == bL0 || b == bL1);
+          if ((v1 - v0) <= SMALL_HULL) {
+            const unsigned c0 = (unsigned)tshfl((int)cm0, b), c1 = (unsigned)tshfl((int)cm1, b), c2 = (unsigned)tshfl((int)cm2, b);
+            im = ((c0 >> lane) & 1u) | (((c1 >> lane) & 1u) << 1) | (((c2 >> lane) & 1u) << 2);
+          } else {
+            im = (b == bL0) ? imL0 : ((b == bL1) ? imL1 : 0xffffffffu);
+          }
+          if (!masked) im = 0xffffffffu;   // (a third large hull, or one beyond 1024 vertices: sweep it)
+          {
+            const int o = sel[0] - v0;     // the deepest vertex is taken
+            if (lane == (o & 31) && (o >> 5) < 32) im &= ~(1u << (o >> 5));
+          }
 #pragma unroll
           for (int pass = 1; pass < 4; pass++) {
             if (!wave_any(!stop)) break;
@@ -931,15 +992,16 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
               flip = c3 > 0.f ? -1.f : 1.f;
             }
             float bx[3] = {0.f, 0.f, 0.f};
-            for (int v = v0 + lane; v < v1; v += TL) {
+            const int nit = (v1 - v0 - lane + TL - 1) / TL;   // strided vertices of this lane
+            auto visit = [&](int v) {
               const float4 h = args.arr.hull[v];
               const float hv[3] = {h.x, h.y, h.z};
               float w[3];
               matvec3(Rb, hv, w);
               const float x0 = rb[0] + w[0], x1 = rb[1] + w[1], x2 = rb[2] + w[2] - h.w;
               const float dd = pos[2] + x2 - floor_z;
-              if (!(dd < margin)) continue;
-              if (v == sel[0] || v == sel[1] || v == sel[2]) continue;
+              if (!(dd < margin)) return;
+              if (v == sel[0] || v == sel[1] || v == sel[2]) return;
               const float dx = x0 - px[0][0], dy = x1 - px[0][1];
               float score;
               if (pass == 1) score = dx * dx + dy * dy;
@@ -948,6 +1010,16 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
                 score = (pass == 2) ? fabsf(cr) : flip * cr;
               }
               if (score > bs) { bs = score; bi = v; bx[0] = x0; bx[1] = x1; bx[2] = x2; }
+            };
+            if (masked) {
+              for (unsigned m = stop ? 0u : im; wave_any(m != 0u); m &= m - 1u) {
+                if (m != 0u) {
+                  const int i = __ffs(m) - 1;
+                  if (i < nit) visit(v0 + lane + TL * i);
+                }
+              }
+            } else {
+              for (int v = v0 + lane; v < v1; v += TL) visit(v);
             }
             const int mine = bi;
             targmax(bs, bi);
@@ -973,6 +1045,9 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
     }
 
     STAMP2(4);
+#if TREX_STAMPS
+    wave_cg += __builtin_amdgcn_s_memtime() - cg_t0;
+#endif
     STAMP(8);
 #if TREX_PRIO_MODE == 2
     {   // wave-level priority for the rest of the substep: total contact rows of the two envs
@@ -1441,7 +1516,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
   const float energy = args.w_energy * power;
 
 #if TREX_STAMPS
-  // per-wave duration and contact counts of its two envs (scripts/wave_balance.py; buffer >= 3 * 4096 floats)
+  // per-wave duration and contact counts of its two envs (scripts/wave_balance.py; buffer >= 4 * 4096 floats)
   if (DEBUG && args.debug && blockIdx.x < 4096) {
     const unsigned long long t_end = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -1449,6 +1524,9 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
     if (threadIdx.x == 0) {
       args.debug[4096 + blockIdx.x] = (float)(t_end - wave_t0);
       args.debug[8192 + blockIdx.x] = (float)(stat_nc + 100 * n1);
+      args.debug[12288 + blockIdx.x] = (float)wave_cg;
+      args.debug[16384 + blockIdx.x] = (float)wave_cg1;
+      args.debug[20480 + blockIdx.x] = (float)wave_cg2;
     }
   }
 #endif
