@@ -26,7 +26,7 @@ def main():
     for t in range(int(sys.argv[1]) if len(sys.argv) > 1 else 230):
         a = sharding.synthetic_actions(ids, t, lo, hi, device=dev)
         b.step(a, obs, rew, done)
-    dbg = torch.zeros(6 * 4096, device=dev)
+    dbg = torch.zeros(7 * 4096, device=dev)
     a = sharding.synthetic_actions(ids, 1000, lo, hi, device=dev)
     b.debug_step(a, obs, dbg)
     torch.cuda.synchronize()
@@ -61,6 +61,21 @@ def main():
             sel = zero & (z >= zl) & (z < zh)
             if sel.any():
                 print("  zero-contact waves with min base z in [%.1f, %.1f): %4d  cycles mean %.3g max %.3g" % (zl, zh, sel.sum(), cyc[sel].mean(), cyc[sel].max()))
+    sel_t = cg - cg1 - cg2
+    cnt = d[24576:24576 + n // 2].astype(np.int64)
+    nb_, np_, nt_ = cnt % 1000, (cnt // 1000) % 1000, cnt // 1000000
+    print("pass B per wave-step: body iterations mean %.1f max %d, passes mean %.1f max %d, candidate trips mean %.1f max %d" % (
+        nb_.mean(), nb_.max(), np_.mean(), np_.max(), nt_.mean(), nt_.max()))
+    A = np.stack([nb_, np_, nt_, np.ones_like(nb_)], 1).astype(float)
+    coef = np.linalg.lstsq(A, sel_t, rcond=None)[0]
+    print("least squares: selection cycles = %.0f per body + %.0f per pass + %.0f per trip + %.0f" % tuple(coef))
+    kk = np.argsort(-sel_t)[:8]
+    print("waves with the longest point selection (selection cycles, contacts env a, env b):",
+          [(int(sel_t[i]), int(n0[i]), int(n1[i])) for i in kk])
+    for lo_, hi_ in ((0, 0), (1, 3), (4, 4), (5, 8), (9, 13)):
+        selw = (np.maximum(n0, n1) >= lo_) & (np.maximum(n0, n1) <= hi_)
+        if selw.any():
+            print("  waves whose heavier env has %d..%d contacts: selection mean %.3g max %.3g" % (lo_, hi_, sel_t[selw].mean(), sel_t[selw].max()))
     k = np.argsort(-cyc)[:8]
     print("slowest waves (cycles, of which contact generation, contacts env a, env b):",
           [(int(cyc[i]), int(cg[i]), int(n0[i]), int(n1[i])) for i in k])

@@ -314,6 +314,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
   __shared__ WaveLds W;
 #if TREX_STAMPS
   const unsigned long long wave_t0 = __builtin_amdgcn_s_memtime();
+  int dbg_bodies = 0, dbg_passes = 0, dbg_trips = 0;   // pass B: body iterations, passes, candidate trips
   unsigned long long wave_cg = 0, wave_cg1 = 0, wave_cg2 = 0;   // cycles in contact generation: all, small-hull scan, large-hull scan
 #endif
   const int lane = threadIdx.x & (TL - 1);
@@ -948,6 +949,9 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       }
       STAMP2(3);
       while (wave_any(active_mask != 0u)) {
+#if TREX_STAMPS
+        dbg_bodies++;
+#endif
         const bool valid = active_mask != 0u;
         const int b = valid ? (__ffs(active_mask) - 1) : 0;
         active_mask &= active_mask - 1u;
@@ -968,7 +972,8 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
           const int v0 = tshfl(hull_v0, b), v1 = tshfl(hull_v1, b);
           // this lane's candidates of body b: bit i <-> vertex v0 + lane + 32 i (in the margin during pass A)
           unsigned im;
-          const bool masked = (v1 - v0) <= 1024 && ((v1 - v0) <= SMALL_HULL || b == bL0 || b == bL1);
+          // (a team without an active body in this trip has stop = true: it must not sweep body 0's hull)
+          const bool masked = stop || ((v1 - v0) <= 1024 && ((v1 - v0) <= SMALL_HULL || b == bL0 || b == bL1));
           if ((v1 - v0) <= SMALL_HULL) {
             const unsigned c0 = (unsigned)tshfl((int)cm0, b), c1 = (unsigned)tshfl((int)cm1, b), c2 = (unsigned)tshfl((int)cm2, b);
             im = ((c0 >> lane) & 1u) | (((c1 >> lane) & 1u) << 1) | (((c2 >> lane) & 1u) << 2);
@@ -983,6 +988,9 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
 #pragma unroll
           for (int pass = 1; pass < 4; pass++) {
             if (!wave_any(!stop)) break;
+#if TREX_STAMPS
+            dbg_passes++;
+#endif
             float bs = -3.0e38f;
             int bi = 0x7fffffff;
             float ex = 0.f, ey = 0.f, flip = 1.f;
@@ -993,8 +1001,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
             }
             float bx[3] = {0.f, 0.f, 0.f};
             const int nit = (v1 - v0 - lane + TL - 1) / TL;   // strided vertices of this lane
-            auto visit = [&](int v) {
-              const float4 h = args.arr.hull[v];
+            auto visit = [&](int v, const float4 h) {
               const float hv[3] = {h.x, h.y, h.z};
               float w[3];
               matvec3(Rb, hv, w);
@@ -1012,14 +1019,26 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
               if (score > bs) { bs = score; bi = v; bx[0] = x0; bx[1] = x1; bx[2] = x2; }
             };
             if (masked) {
-              for (unsigned m = stop ? 0u : im; wave_any(m != 0u); m &= m - 1u) {
-                if (m != 0u) {
-                  const int i = __ffs(m) - 1;
-                  if (i < nit) visit(v0 + lane + TL * i);
+              constexpr int UC = 4;   // candidates per trip: their loads are issued together
+              for (unsigned m = stop ? 0u : im; wave_any(m != 0u);) {
+#if TREX_STAMPS
+                dbg_trips++;
+#endif
+                int vi[UC];
+                float4 hc[UC];
+#pragma unroll
+                for (int u = 0; u < UC; u++) {
+                  const int i = m != 0u ? (__ffs(m) - 1) : 32;
+                  m &= m - 1u;            // (0 stays 0)
+                  vi[u] = i < nit ? v0 + lane + TL * i : -1;
+                  hc[u] = args.arr.hull[vi[u] >= 0 ? vi[u] : v0];
                 }
+#pragma unroll
+                for (int u = 0; u < UC; u++)
+                  if (vi[u] >= 0) visit(vi[u], hc[u]);
               }
             } else {
-              for (int v = v0 + lane; v < v1; v += TL) visit(v);
+              for (int v = v0 + lane; !stop && v < v1; v += TL) visit(v, args.arr.hull[v]);
             }
             const int mine = bi;
             targmax(bs, bi);
@@ -1527,6 +1546,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       args.debug[12288 + blockIdx.x] = (float)wave_cg;
       args.debug[16384 + blockIdx.x] = (float)wave_cg1;
       args.debug[20480 + blockIdx.x] = (float)wave_cg2;
+      args.debug[24576 + blockIdx.x] = (float)(dbg_bodies + 1000 * dbg_passes + 1000000 * dbg_trips);
     }
   }
 #endif
