@@ -26,7 +26,7 @@ def main():
     for t in range(int(sys.argv[1]) if len(sys.argv) > 1 else 230):
         a = sharding.synthetic_actions(ids, t, lo, hi, device=dev)
         b.step(a, obs, rew, done)
-    dbg = torch.zeros(7 * 4096, device=dev)
+    dbg = torch.zeros(12 * 4096, device=dev)
     a = sharding.synthetic_actions(ids, 1000, lo, hi, device=dev)
     b.debug_step(a, obs, dbg)
     torch.cuda.synchronize()
@@ -61,6 +61,13 @@ def main():
             sel = zero & (z >= zl) & (z < zh)
             if sel.any():
                 print("  zero-contact waves with min base z in [%.1f, %.1f): %4d  cycles mean %.3g max %.3g" % (zl, zh, sel.sum(), cyc[sel].mean(), cyc[sel].max()))
+    ph = np.stack([d[28672 + 4096 * i: 28672 + 4096 * i + n // 2] for i in range(5)], 1)
+    names = ["tree phases", "contact generation", "chain walk + row build", "solver sweeps", "results, integrate, epilogue FK"]
+    print("per-wave phase cycles (mean over the waves | mean over the slowest 5 %% of the waves):")
+    slow = cyc >= np.percentile(cyc, 95)
+    for i, nm in enumerate(names):
+        print("  %-32s %9.3g (%4.1f %%) | %9.3g (%4.1f %%)" % (nm, ph[:, i].mean(), 100 * ph[:, i].mean() / ph.sum(1).mean(),
+                                                            ph[slow, i].mean(), 100 * ph[slow, i].mean() / ph[slow].sum(1).mean()))
     sel_t = cg - cg1 - cg2
     cnt = d[24576:24576 + n // 2].astype(np.int64)
     nb_, np_, nt_ = cnt % 1000, (cnt // 1000) % 1000, cnt // 1000000

@@ -312,9 +312,14 @@ struct KernelArgs {
 template <bool RESET, bool DEBUG>
 __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
   __shared__ WaveLds W;
+#if !TREX_STAMPS
+#define WPH(i) do {} while (0)
+#endif
 #if TREX_STAMPS
   const unsigned long long wave_t0 = __builtin_amdgcn_s_memtime();
   int dbg_bodies = 0, dbg_passes = 0, dbg_trips = 0;   // pass B: body iterations, passes, candidate trips
+  unsigned long long wph[5] = {0, 0, 0, 0, 0}, wph_t = wave_t0;   // per-wave phase cycles: tree, contacts, walk+build, sweeps, rest
+#define WPH(i) do { const unsigned long long _w = __builtin_amdgcn_s_memtime(); wph[i] += _w - wph_t; wph_t = _w; } while (0)
   unsigned long long wave_cg = 0, wave_cg1 = 0, wave_cg2 = 0;   // cycles in contact generation: all, small-hull scan, large-hull scan
 #endif
   const int lane = threadIdx.x & (TL - 1);
@@ -799,6 +804,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
     }
 
     STAMP(7);
+    WPH(0);
 #if TREX_STAMPS
     const unsigned long long cg_t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1068,6 +1074,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
     wave_cg += __builtin_amdgcn_s_memtime() - cg_t0;
 #endif
     STAMP(8);
+    WPH(1);
 #if TREX_PRIO_MODE == 2
     {   // wave-level priority for the rest of the substep: total contact rows of the two envs
       const int tot = __builtin_amdgcn_readlane(nc, 0) + __builtin_amdgcn_readlane(nc, 32);
@@ -1322,6 +1329,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       }
       __syncthreads();
       STAMP(10);
+      WPH(2);
       // The launch lasts as long as its heaviest wave: let a wave with many rows win the issue arbitration
       // against its lighter SIMD partner.
 #if TREX_PRIO_MODE == 1
@@ -1402,6 +1410,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       __builtin_amdgcn_s_setprio(0);
 #endif
       STAMP(12);
+      WPH(3);
 #if TREX_STAMPS
       if (DEBUG && args.debug && blockIdx.x == 0 && threadIdx.x == 0) {
         args.debug[3000 + 16 * sub + 14] += (float)acc_joint;
@@ -1516,6 +1525,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       stat_imp = nimp;
     }
     STAMP(13);
+    WPH(4);
   }
 
   // ---- head position (needs FK at the new pose: getLinkState(computeForwardKinematics=1))
@@ -1547,6 +1557,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       args.debug[16384 + blockIdx.x] = (float)wave_cg1;
       args.debug[20480 + blockIdx.x] = (float)wave_cg2;
       args.debug[24576 + blockIdx.x] = (float)(dbg_bodies + 1000 * dbg_passes + 1000000 * dbg_trips);
+      for (int i = 0; i < 5; i++) args.debug[28672 + 4096 * i + blockIdx.x] = (float)wph[i];
     }
   }
 #endif
