@@ -348,7 +348,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
   // it, through an opaque pointer, so that no constant is live - and spilled - across the solver loop.
   auto Mo = [&]() { const TrexDeviceModel *Mi = M; asm volatile("" : "+s"(Mi)); return Mi; };
   int anc[MAXD];
-  float axis[3], jpos[3], jrot[9], comb[3], inb[6], sph[3], boxh[3];
+  float axis[3], jpos[3], jrot[9], comb[3], inb[6];
   float mass = 0.f, mscale = 1.f, jdamp = 0.f;
   auto load_body_constants = [&]() {
     const TrexDeviceModel *Mi = Mo();
@@ -361,8 +361,6 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
     for (int c = 0; c < 9; c++) jrot[c] = Mi->jrot[c][lane];
 #pragma unroll
     for (int c = 0; c < 6; c++) inb[c] = Mi->inertia[c][lane];
-#pragma unroll
-    for (int c = 0; c < 3; c++) { sph[c] = Mi->sphere[c][lane]; boxh[c] = Mi->box_half[c][lane]; }
   };
   const int nj = nb - 1;
 
@@ -820,6 +818,9 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       const TrexDeviceModel *Mi = Mo();
       const int hull_v0 = Mi->hull_start[lane < nb ? lane : nb], hull_v1 = Mi->hull_start[lane < nb ? lane + 1 : nb];
       float sc[3];
+      float sph[3], boxh[3];   // read here, not at the top of the substep: not carried across the ABA passes
+#pragma unroll
+      for (int c = 0; c < 3; c++) { sph[c] = Mi->sphere[c][lane]; boxh[c] = Mi->box_half[c][lane]; }
       matvec3(R, sph, sc);
       // broad phase: lowest point of the hull's oriented bounding box (conservative, much tighter than
       // a sphere for the long bones): z_centre - sum_k |R_zk| half_k
@@ -1151,6 +1152,12 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
         // lanes write, the others only walk): nothing but the three running forces p[a] is carried.
         const bool has = lane < nc;
         const bool st = (team == e) && lane < MAXC;
+        int anc_w[MAXD];   // re-read (L2-resident model): not carried across contact generation and the other env's solve
+        {
+          const TrexDeviceModel *Mi = Mo();
+#pragma unroll
+          for (int d = 0; d < MAXD; d++) anc_w[d] = is_body ? Mi->anc[d][lane] : -1;
+        }
         float *colf = reinterpret_cast<float *>(W.u.rows.col[CROW0 + 3 * (st ? lane : 0)]);   // 20 words per row
         float *ownf = W.u.rows.own[CROW0 + 3 * (st ? lane : 0)];                               // 15 words per row
         // updated body velocities (after the unconstrained step) for the row right-hand sides
@@ -1176,7 +1183,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
           int ca = -1;
           float ua[3] = {0.f, 0.f, 0.f}, zc[3] = {0.f, 0.f, 0.f};
           if (d <= maxdepth) {
-            const int ab = tshfl(anc[d - 1], cbody);
+            const int ab = tshfl(anc_w[d - 1], cbody);
             ca = has ? ab : -1;
             const int src = ab < 0 ? 0 : ab;
             float aa[3], Uda[6], ra[3];
