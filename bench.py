@@ -8,12 +8,19 @@ A "step" is one TrexBulletEnv.step() of every env: ONE launch of the fused HIP k
 (5 substeps x 60 solver iterations, trex_env.py:71-73). Workload at N=1 = BASELINE config 2:
 4096 envs, trex.urdf, uniform random actions in the joint limits, inputs resident in HBM.
 For N>1 every rank owns 4096 envs (weak scaling, BASELINE config 4) and each step ends with the
-RCCL all-gather of the observation rows (the path's only collective).
+RCCL all-gather of the [obs | reward | done] row block (the path's only collective).
+
+The timed window is STATIONARY: episode phases are staggered (env i's 1000-step episode starts
+i*1000/N steps after env 0's), an untimed pre-roll of one full episode length brings every env to a
+different age, and the same schedule (a masked reset of the ~N/1000 envs whose episode ends) runs in
+every step, so any --steps / --warmup times the same mix of free fall, touchdown and flailing on the
+ground. `state_mix` in the JSON line holds the contact-count histogram at both ends of the window.
 
 The JSON line carries `roofline` (algorithmic 912 B/env-step over the kernel's hipEvent-timed
 duration vs the 8 TB/s HBM peak; the kernel is latency/VALU bound so the fraction is tiny - see
-DESIGN.md) and, at N=1, `cpu_baseline`: the f64 CPU oracle (a port; pybullet is absent) timed on
-the host cores on the same kind of workload.
+DESIGN.md), `roofline_issue` (VALU instructions per launch, from the committed SQ counters of the
+SAME kernel build, over the live launch duration vs the chip's VALU issue peak) and, at N=1,
+`cpu_baseline`: the f64 CPU oracle (a port; pybullet is absent) timed on the host cores.
 """
 import argparse
 import json
@@ -26,12 +33,17 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "trex-gym_amd"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+# VALU issue peak: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles per SIMD at 2.4 GHz
+# (MI355X_MICROARCH.md, chip parameters + "v_fma_f32 (wave64) 2 cyc")
+VALU_ISSUE_PEAK_GIPS = 256 * 4 * 2.4 / 2.0   # 1228.8 G wave-instructions/s
 EPISODE_STEPS = 1000   # harness time limit (the reference never terminates, trex_env.py:183-184)
 
 
 def _cpu_worker(args):
-    """One host core: reset + random-action steps of one env with the f64 oracle for ~budget s."""
-    seed, budget = args
+    """One host core, one env, f64 oracle. mode "random": reset + random-action steps for ~budget s
+    (the GPU workload); mode "config1": BASELINE config 1 = zero action, 50 warm-up + 1000 timed steps
+    (trex_env.py:128-154 driven as BASELINE.md section 2 states)."""
+    seed, budget, mode = args
     import numpy as np
     from oracle import oracle as O, trex_model as tm
     m = tm.compile_model(O.default_asset_urdf())
@@ -40,6 +52,14 @@ def _cpu_worker(args):
     rng = np.random.default_rng(seed)
     s = orc.new_state()
     orc.reset(s)
+    if mode == "config1":
+        zero = np.zeros(len(lo))
+        for _ in range(50):
+            orc.step(s, zero)
+        t0 = time.perf_counter()
+        for _ in range(1000):
+            orc.step(s, zero)
+        return 1000, time.perf_counter() - t0
     for _ in range(20):
         orc.step(s, rng.uniform(lo, hi))
     n, t0 = 0, time.perf_counter()
@@ -52,12 +72,14 @@ def _cpu_worker(args):
     return n, time.perf_counter() - t0
 
 
-def cpu_baseline(budget_s=12.0):
+def cpu_baseline(budget_s=10.0):
     import multiprocessing as mp
     cores = min(len(os.sched_getaffinity(0)), 16)
     ctx = mp.get_context("spawn")
     with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(i, budget_s) for i in range(cores)])
+        one = pool.map(_cpu_worker, [(0, 0.0, "config1")])[0]                       # (i) single core
+        many = pool.map(_cpu_worker, [(i, 0.0, "config1") for i in range(cores)])   # (ii) P processes
+        res = pool.map(_cpu_worker, [(i, budget_s, "random") for i in range(cores)])
     total = sum(n for n, _ in res)
     wall = max(t for _, t in res)
     try:
@@ -68,7 +90,16 @@ def cpu_baseline(budget_s=12.0):
     return {"value": total / wall, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": "f64 C oracle (oracle/trex_oracle.c), %d processes x 1 env, reset + uniform random "
                       "actions for %.0f s each (%d env-steps total)" % (cores, budget_s, total),
+            "config1_zero_action": {
+                "workload": "BASELINE config 1: 1 env per process, zero action, 50 warm-up + 1000 timed steps",
+                "single_core_env_steps_per_s": one[0] / one[1],
+                "all_cores_env_steps_per_s": cores * 1000 / max(t for _, t in many), "processes": cores},
             "pybullet": pb}
+
+
+def _load_json(name):
+    p = os.path.join(ROOT, "profiles", name)
+    return json.load(open(p)) if os.path.exists(p) else None
 
 
 def main():
@@ -77,6 +108,8 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--preroll", type=int, default=EPISODE_STEPS,
+                    help="untimed steps before the warm-up that stagger the episode phases (default: one episode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--collision", choices=["hulls", "primitives"], default="hulls",
                     help="primitives: capsules/spheres fitted to the hulls (148 points instead of 2181 vertices); not the headline config")
@@ -103,7 +136,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from trex_gym import sharding
+    from trex_gym import _capi, sharding
     from trex_gym.vec_env import TrexVecEnv
 
     if os.environ.get("TREX_BENCH_SHARE_DEVICE"):   # rehearsal of the N>1 path on a one-GPU box
@@ -114,6 +147,7 @@ def main():
     if world > 1 or under_launcher:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    rccl_ranks = dist.get_world_size() if dist.is_initialized() else 1
 
     n_global = args.envs_per_gpu * world
     overrides = {k: float(v) for k, v in (p.split("=") for p in args.param)}
@@ -131,10 +165,19 @@ def main():
     pool = torch.stack([sharding.synthetic_actions(ids, t, mid - half, mid + half, seed=0, device=dev) for t in range(16)])
     if args.action_scale != 1.0:
         overrides = dict(overrides, action_scale=args.action_scale)
+    # staggered episodes, keyed by the GLOBAL env id: env i is reset at the steps t with
+    # (t + phase_i) % EPISODE_STEPS == 0. One uint8 mask per residue, built once (no per-step torch glue).
+    phase = (ids * EPISODE_STEPS) // n_global
+    reset_masks = [None] * EPISODE_STEPS
+    for k in range(EPISODE_STEPS):
+        m = (phase == k)
+        if bool(m.any().item()):
+            reset_masks[k] = m.to(torch.uint8).contiguous()
 
     events = []
     force_gather = under_launcher and world == 1 and bool(os.environ.get("TREX_BENCH_FORCE_GATHER"))
-    pipe = (sharding.PipelinedGather(env.num_envs, env.obs.shape[1], 1, env.obs.dtype, dev) if force_gather else None)
+    pipe = (sharding.PipelinedGather(env.num_envs, env.rows.shape[1], 1, env.rows.dtype, dev) if force_gather else None)
+    gather_mode = ["pipelined"]
 
     def run(n_steps, t_base, timed=False):
         for t in range(n_steps):
@@ -145,12 +188,16 @@ def main():
             if timed:
                 e1.record()
                 events.append((e0, e1))
+            mk = reset_masks[(-(t_base + t + 1)) % EPISODE_STEPS]
+            if mk is not None:
+                env.reset_tensor(mk)      # episode limit of the harness: ~N/1000 envs per step
             if world > 1:
-                env.all_gather_obs_pipelined()   # overlaps the next step; consumer sees obs one step late
+                if gather_mode[0] == "pipelined":
+                    env.all_gather_rows_pipelined()   # overlaps the next step; consumer sees rows one step late
+                else:
+                    env.all_gather_rows()             # blocking: the consumer sees this step's rows
             elif force_gather:   # one-GPU rehearsal of the collective call itself (RCCL, world of 1)
-                pipe.push(env.obs)
-            if (t_base + t + 1) % EPISODE_STEPS == 0:
-                env.reset_tensor()
+                pipe.push(env.rows)
 
     def fence():
         torch.cuda.synchronize()
@@ -158,13 +205,39 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def contact_hist():
+        cnt = torch.zeros(n_local, dtype=torch.int32, device=dev)
+        env.batch.contact_stats(cnt, None)
+        h = torch.bincount(cnt.clamp(0, 15).to(torch.int64), minlength=16)
+        return [int(x) for x in h.tolist()[:14]]
+
     env.reset_tensor()
-    run(args.warmup, 0)
+    run(args.preroll, 0)
+    t_base = args.preroll
+    blocking_ms = None
+    if world > 1:   # the blocking form of the exchange, reported beside the pipelined one (not `value`)
+        gather_mode[0] = "blocking"
+        nb = max(10, min(args.steps, 50))
+        run(5, t_base)
+        fence()
+        tb = time.perf_counter()
+        run(nb, t_base + 5)
+        fence()
+        blocking_ms = (time.perf_counter() - tb) / nb * 1e3
+        tm_ = torch.tensor([blocking_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(tm_, op=dist.ReduceOp.MAX)
+        blocking_ms = tm_.item()
+        t_base += 5 + nb
+        gather_mode[0] = "pipelined"
+    run(args.warmup, t_base)
+    fence()
+    hist0 = contact_hist()
     fence()
     t0 = time.perf_counter()
-    run(args.steps, args.warmup, timed=True)
+    run(args.steps, t_base + args.warmup, timed=True)
     fence()
     dt = time.perf_counter() - t0
+    hist1 = contact_hist()
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -174,13 +247,27 @@ def main():
     kernel_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)
     finite = bool(torch.isfinite(env.obs).all().item())
     info = env.batch.launch_info()
+    build_id = _capi.build_id()
     if rank == 0:
         alg = (info["alg_bytes_per_env_step"] + (1044 if args.domain_rand else 0)) * n_local  # bytes per launch
         achieved = alg / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        # PMC-derived numbers are only quoted when they were collected on THIS kernel build and workload
+        headline = args.envs_per_gpu == 4096 and not overrides and not args.domain_rand
+        tj, sj = _load_json("pmc_traffic.json"), _load_json("sq_counters.json")
+        traffic = tj["hbm_bytes_per_launch"] if (tj and headline and tj.get("build_id") == build_id) else None
+        traffic_note = ("PMC FETCH_SIZE x2 + WRITE_SIZE (MI355X_MICROARCH.md), collected on build %s by "
+                        "profiles/tools/run_profiles.sh; live re-measurement needs rocprofv3" % build_id) if traffic else \
+            "null: no PMC collection for kernel build %s (profiles/pmc_traffic.json is from build %s)" % (
+                build_id, tj.get("build_id") if tj else None)
+        issue = None
+        if sj and headline and sj.get("build_id") == build_id:
+            ips = sj["valu_insts_per_launch"] / (kernel_ms * 1e-3) / 1e9
+            issue = {"bound": "valu_issue", "achieved": ips, "peak": VALU_ISSUE_PEAK_GIPS, "unit": "G wave-instr/s",
+                     "frac": ips / VALU_ISSUE_PEAK_GIPS,
+                     "valu_insts_per_launch": sj["valu_insts_per_launch"], "waves_per_simd": sj.get("waves_per_simd"),
+                     "mean_wave_lifetime_frac": sj.get("mean_wave_lifetime_frac"),
+                     "source": "SQ_INSTS_VALU of build %s (profiles/sq_counters.json) / live kernel_ms; peak = 1024 SIMDs "
+                               "x one wave64 VALU instruction per 2 cycles x 2.4 GHz" % build_id}
         out = {
             "metric": "env-steps/sec (whole node), trex.urdf 4096 envs per MI355X",
             "value": n_global * args.steps / dt,
@@ -192,25 +279,33 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "rccl_ranks": rccl_ranks,
             "config": {"workload": "%d envs per GPU x %d GPU(s), trex.urdf (26 bodies, 31 dof, 2181 hull "
                                    "vertices), uniform random actions keyed by global env id, 5 substeps x 60 "
-                                   "PGS iterations per step, episode limit %d steps%s"
-                                   % (args.envs_per_gpu, world, EPISODE_STEPS,
-                                      ", obs all-gather over RCCL each step, overlapped with the next step (gathered rows are one step old)" if world > 1 else ""),
+                                   "PGS iterations per step, episode limit %d steps with staggered phases "
+                                   "(pre-roll %d untimed steps)%s"
+                                   % (args.envs_per_gpu, world, EPISODE_STEPS, args.preroll,
+                                      ", [obs|reward|done] all-gather over RCCL each step, overlapped with the next step (gathered rows are one step old)" if world > 1 else ""),
                        "envs_global": n_global, "parallelism": "env-sharded dp%d" % world,
                        **({"domain_randomisation": "mass_scale U(0.8,1.2) per body, friction U(0.5,1.25), seed 1"}
                           if args.domain_rand else {}),
                        **({"ABLATION_param_overrides": overrides} if overrides else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": "trex_step_kernel<false, false>", "kernel_ms": kernel_ms,
-                         "kernel_ms_covers": "one step launch = trex_pair_kernel (about 7 us: wave pairing by contact "
-                                             "count) + trex_step_kernel<false, false>, bracketed by HIP events",
-                         "alg_bytes_per_launch": alg,
+                         "kernel_ms_covers": "one step launch (balance kernel, about 7 us, + trex_step_kernel<false, false>), "
+                                             "bracketed by HIP events; the masked episode-limit reset launch is outside it",
+                         "alg_bytes_per_launch": alg, "kernel_build": build_id,
                          "note": "latency/VALU-bound by construction (serial PGS); HBM fraction reported as "
-                                 "BASELINE asks, see DESIGN.md for the instruction-issue roofline"},
+                                 "BASELINE asks, roofline_issue is the bound that matters (DESIGN.md)"},
+            "roofline_issue": issue,
+            "state_mix": {"contacts_per_env_histogram_0_to_13": {"window_start": hist0, "window_end": hist1},
+                          "mean_contacts": [sum(i * c for i, c in enumerate(h)) / max(1, sum(h)) for h in (hist0, hist1)]},
             "outputs_finite": finite,
         }
+        if blocking_ms is not None:
+            out["gather"] = {"pipelined_ms_per_step": dt / args.steps * 1e3, "blocking_ms_per_step": blocking_ms,
+                             "row_block": "[n, 3J+2] f32 = obs | reward | done"}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))

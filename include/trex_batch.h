@@ -13,7 +13,10 @@
  *     shared by several batches; a TrexBatch is bound to one HIP device, is not re-entrant,
  *     and all of its calls are asynchronous and ordered on the hipStream_t given
  *     (passed as void* so the header needs no HIP include; NULL = the default stream).
- *   - "device" pointers are caller-owned HIP device buffers (e.g. torch tensors' data_ptr()).
+ *   - "device" pointers are caller-owned HIP device buffers (e.g. torch tensors' data_ptr()) on the
+ *     batch's device. Every batch call validates each distinct pointer once (hipPointerGetAttributes +
+ *     allocation range, cached per batch): host memory, another device's memory or a buffer shorter than
+ *     the call needs returns TREX_E_INVALID instead of faulting the GPU.
  *   - joints are always exposed in the reference's observation order: revolute joint names
  *     sorted (trex_robot.py:311-314); J = trex_model_num_joints() (25 for trex.urdf).
  */
@@ -38,6 +41,9 @@ typedef struct TrexModel TrexModel;
 typedef struct TrexBatch TrexBatch;
 
 const char *trex_last_error(void);
+/* Identifies the kernel build (hash of the kernel sources, set by the Makefile): profiles/ records the
+ * build its counters were collected on, bench.py quotes them only for a matching build. */
+const char *trex_build_id(void);
 
 /* ---- model: replaces loadURDF + the getJointInfo/getDynamicsInfo/getNumJoints introspection
  *      of trex_robot.py:47-56,98-117,158,175-187,294-320 and the floor of trex_env.py:103 ---- */
@@ -118,6 +124,14 @@ int trex_batch_reset(TrexBatch *batch, const uint8_t *mask_dev, float *obs_out_d
  *                         (the three values logged at trex_env.py:193-195) */
 int trex_batch_step(TrexBatch *batch, const float *actions_dev, float *obs_dev, float *reward_dev,
                     uint8_t *done_dev, float *penalties_dev, void *stream);
+
+/* The same two calls writing ONE row block (what the multi-GPU exchange gathers):
+ *   rows_dev [N, row_stride] f32 device, row_stride >= 3J + 2:
+ *     [0, 3J) observation, [3J] reward, [3J+1] done as 0.0 / 1.0; columns beyond 3J+2 are not touched.
+ * trex_batch_reset_rows writes the observation columns only (of every env, reset or not). */
+int trex_batch_step_rows(TrexBatch *batch, const float *actions_dev, float *rows_dev, int row_stride,
+                         float *penalties_dev, void *stream);
+int trex_batch_reset_rows(TrexBatch *batch, const uint8_t *mask_dev, float *rows_dev, int row_stride, void *stream);
 
 /* env state [N, 13 + 2J] f32 device: base position(3), base orientation quaternion xyzw(4) - both
  * of the base INERTIAL frame as resetBasePositionAndOrientation/getBasePositionAndOrientation

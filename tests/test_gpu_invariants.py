@@ -160,15 +160,18 @@ def test_step_is_graph_capturable_and_stream_ordered():
     graph = TrexVecEnv(n, urdf_path=ASSET_URDF, device=DEV)
     eager.reset_tensor(); graph.reset_tensor()
     torch.cuda.synchronize()
+    graph.batch.step_rows(a, graph.rows, graph.penalties)   # (first call validates the buffers; not captured)
+    eager.batch.step_rows(a, eager.rows, eager.penalties)
+    torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):            # captures on a side stream; _capi passes torch's current stream down
-        graph.batch.step(a, graph.obs, graph.rew, graph.done, graph.penalties)
+        graph.batch.step_rows(a, graph.rows, graph.penalties)
     for t in range(12):
         a.copy_(0.3 * torch.sin(torch.arange(25, device=DEV) + t).expand(n, 25))
         g.replay()
-        eager.batch.step(a, eager.obs, eager.rew, eager.done, eager.penalties)
+        eager.batch.step_rows(a, eager.rows, eager.penalties)
     torch.cuda.synchronize()
-    assert (graph.obs == eager.obs).all() and (graph.rew == eager.rew).all()
+    assert (graph.rows == eager.rows).all() and (graph.penalties == eager.penalties).all()
     assert (graph.get_state() == eager.get_state()).all()
 
 
@@ -179,7 +182,8 @@ def test_launch_info_and_event_timing(capi=None):
     info = v.batch.launch_info()
     assert info["grid"] == 500 and info["block"] == 64 and info["alg_bytes_per_env_step"] == 912
     assert 0 < info["lds_bytes"] <= 20 * 1024          # 8 workgroups per CU must fit the 160 KB of LDS
-    ms = v.batch.time_steps(torch.zeros(1000, 25, device=DEV), v.obs, v.rew, v.done, 5)
+    ms = v.batch.time_steps(torch.zeros(1000, 25, device=DEV), torch.zeros(1000, 75, device=DEV),
+                            torch.zeros(1000, device=DEV), torch.zeros(1000, dtype=torch.uint8, device=DEV), 5)
     assert 0.05 < ms < 50
 
 
@@ -245,5 +249,6 @@ def test_cpp_caller_of_the_c_abi():
     r = subprocess.run([exe, ASSET_URDF, "1024", "50"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert "26 bodies, 25 joints (132 URDF joints), 2181 hull vertices" in r.stdout
+    assert "bad buffers refused" in r.stdout     # host pointer / short buffer -> TREX_E_INVALID, no GPU fault
     rate = float(r.stdout.strip().splitlines()[-1].split("=")[-1].split()[0])
     assert rate > 1e5

@@ -297,10 +297,24 @@ def test_wave_pairing_and_contact_budget(full):
     assert (o1 == o2).all() and (r1 == r2).all() and (s1 == v.get_state()).all()
 
 
-def test_host_tensors_are_refused(full, capi):
+def test_bad_tensors_are_refused(full, capi):
+    """Host memory, a wrong dtype, a short or non-contiguous buffer would be misread or fault the GPU:
+    the binding refuses them with TREX_E_INVALID (and the C-ABI checks raw pointers again:
+    tests/test_gpu_invariants.py::test_cpp_caller_of_the_c_abi)."""
     v, lo, hi = full
+    obs, rew = torch.zeros(N_FULL, 75, device=DEV), torch.zeros(N_FULL, device=DEV)
+    done, a = torch.zeros(N_FULL, dtype=torch.uint8, device=DEV), torch.zeros(N_FULL, 25, device=DEV)
+    for bad in ((a.cpu(), obs, rew, done),                    # host memory
+                (a, obs, rew, done.to(torch.int32)),          # wrong dtype
+                (a, obs[: N_FULL // 2], rew, done),           # too short
+                (a, v.obs, rew, done),                        # a strided view (columns of the row block)
+                (a.double(), obs, rew, done)):
+        with pytest.raises(capi.TrexError) as ei:
+            v.batch.step(*bad)
+        assert ei.value.code == capi.E_INVALID
     with pytest.raises(capi.TrexError):
-        v.batch.step(torch.zeros(N_FULL, 25), v.obs, v.rew, v.done)   # host memory: would fault the GPU
+        v.batch.step_rows(a, torch.zeros(N_FULL, 76, device=DEV))   # row block narrower than 3J + 2
+    v.batch.step(a, obs, rew, done)                           # and the well-formed call still works
 
 
 def test_full_clipping_equals_clipped_actions(full):
@@ -349,6 +363,44 @@ def test_reward_is_the_reference_formula(full):
     want = -1.0 * (2.5 - head[:, 2]) ** 2 - 0.002 * (head[:, 0] ** 2 + head[:, 1] ** 2) - 0.005 * power
     assert torch.allclose(rew.double(), want, rtol=2e-4, atol=1e-3)
     assert torch.allclose(v.penalties.double().sum(1), -rew.double(), rtol=1e-5, atol=1e-4)
+
+
+def test_config4_size_on_one_gpu(oracle64, model):
+    """BASELINE config 4's batch (32 768 envs) on ONE GPU: the same launch path at 8x the headline grid.
+    Determinism, permutation equivariance, finiteness, the 13-point budget - and one-step oracle parity
+    on 64 of those states (sampled across the contact-count range)."""
+    n = 32768
+    v = make_vec(n)
+    lo = torch.tensor(model["q_lower"][model["obs_order"]], dtype=torch.float32, device=DEV)
+    hi = torch.tensor(model["q_upper"][model["obs_order"]], dtype=torch.float32, device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    v.reset_tensor()
+    for t in range(60):      # through touchdown: contact counts from 0 up to the budget
+        v.step_tensor((lo + (hi - lo) * torch.rand(n, 25, device=DEV, generator=g)).contiguous())
+    st = v.get_state().clone()
+    a = (lo + (hi - lo) * torch.rand(n, 25, device=DEV, generator=g)).contiguous()
+    o1, r1, _ = v.step_tensor(a)
+    o1, r1, s1 = o1.clone(), r1.clone(), v.get_state().clone()
+    cnt = torch.zeros(n, dtype=torch.int32, device=DEV)
+    v.batch.contact_stats(cnt, None)
+    assert torch.isfinite(o1).all() and torch.isfinite(r1).all() and torch.isfinite(s1).all()
+    assert 0 <= int(cnt.min()) and int(cnt.max()) <= 13 and int(cnt.max()) >= 6
+    v.set_state(st)                                   # determinism
+    o2, r2, _ = v.step_tensor(a)
+    assert (o2 == o1).all() and (r2 == r1).all() and (v.get_state() == s1).all()
+    perm = torch.randperm(n, device=DEV, generator=g)   # permutation equivariance
+    v.set_state(st[perm].contiguous())
+    o3, r3, _ = v.step_tensor(a[perm].contiguous())
+    assert (o3 == o1[perm]).all() and (r3 == r1[perm]).all() and (v.get_state() == s1[perm]).all()
+    # oracle parity on a 64-env sample: the 32 envs with the most contacts + 32 spread over the batch
+    idx = torch.cat([torch.argsort(cnt, descending=True)[:32], torch.arange(0, n, n // 32, device=DEV)[:32]]).cpu().numpy()
+    st_h, a_h, o_h, r_h, c_h = st.cpu().numpy(), a.cpu().numpy(), o1.cpu().numpy(), r1.cpu().numpy(), cnt.cpu().numpy()
+    for e in idx:
+        s = oracle64.new_state()
+        oracle64.set_state(s, st_h[e].astype(np.float64))
+        o, r, _ = oracle64.step(s, a_h[e].astype(np.float64))
+        assert_step_close(o_h[e], o, r_h[e], r, "config-4 env %d (%d contacts)" % (e, c_h[e]))
+        assert len(oracle64.contacts(s)[0]) == c_h[e]
 
 
 @pytest.mark.parametrize("n", [1, 3, 63, 4095])

@@ -1,6 +1,7 @@
 """The N>1 path on CPU: world_size-2 gloo processes shard the env ids, generate actions keyed by the
 GLOBAL env id, advance their shard (with the CPU oracle standing in for the GPU kernel - this is a
-test) and all-gather the observation rows. The gathered result must equal the single-process run."""
+test) and all-gather the [obs | reward | done] row block - blocking and pipelined. The
+gathered result must equal the single-process run."""
 import os
 import socket
 
@@ -62,11 +63,15 @@ def _rollout(env_ids, steps):
         orc.reset(s)
         states.append(s)
     obs = np.zeros((len(env_ids), 75), np.float32)
+    rew = np.zeros(len(env_ids), np.float32)
+    done = np.zeros(len(env_ids), bool)
     for t in range(steps):
         a = sharding.synthetic_actions(env_ids, t, lo, hi, seed=0).numpy()
         for k, s in enumerate(states):
-            obs[k] = orc.step(s, a[k].astype(np.float64))[0]
-    return torch.from_numpy(obs)
+            obs[k], rew[k], _ = orc.step(s, a[k].astype(np.float64))
+            done[k] = (env_ids[k] + t) % 3 == 0     # a harness flag, so that the done column is exercised
+    # the row block the exchange carries: obs | reward | done
+    return sharding.pack_rows(torch.from_numpy(obs), torch.from_numpy(rew), torch.from_numpy(done))
 
 
 def _worker(rank, world, port, n_global, steps, ret):
@@ -94,9 +99,14 @@ def test_two_rank_gloo_gather_equals_single_process(n_global):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, n_global, steps, ret), nprocs=2, join=True)
     got = ret["gathered"]
-    assert got.shape == want.shape
+    assert got.shape == want.shape == (n_global, 77)
     assert torch.equal(got, want)
     assert not torch.equal(want[0], want[1])   # different global ids -> different actions -> rows
+    from trex_gym import sharding
+    obs, rew, done = sharding.split_rows(got)
+    assert obs.shape == (n_global, 75) and rew.shape == (n_global,) and done.dtype == torch.bool
+    assert (rew < 0).all()                       # the reward column arrived (trex_env.py:192 is a sum of penalties)
+    assert done.tolist() == [(i + steps - 1) % 3 == 0 for i in range(n_global)]
 
 
 def _pipe_worker(rank, world, port, ret):
@@ -109,7 +119,10 @@ def _pipe_worker(rank, world, port, ret):
     pipe = sharding.PipelinedGather(3, 5, world, torch.float32, "cpu")
     got = []
     for t in range(4):
-        local = torch.full((3, 5), float(10 * t + rank))
+        # obs (3 columns) | reward | done packed like the step kernel writes them
+        local = sharding.pack_rows(torch.full((3, 3), float(10 * t + rank)), torch.full((3,), float(10 * t + rank)),
+                                   torch.full((3,), 10 * t + rank, dtype=torch.int32))
+        assert local.shape == (3, 5)
         prev = pipe.push(local)
         local.fill_(-1.0)    # the caller may overwrite its rows at once (they were staged)
         got.append(None if prev is None else prev.clone())

@@ -14,9 +14,9 @@
 
 extern "C" {
 hipError_t trex_launch_step(const TrexDeviceModel *, TrexBatchArrays, int, const float *, float *, float *, uint8_t *,
-                            float *, float, float, float, float *, hipStream_t);
+                            float *, float, float, float, float *, hipStream_t, float *, int, int);
 hipError_t trex_launch_reset(const TrexDeviceModel *, TrexBatchArrays, int, const uint8_t *, float *, float, float,
-                             float, float *, hipStream_t);
+                             float, float *, hipStream_t, int);
 hipError_t trex_launch_pack_state(const TrexDeviceModel *, TrexBatchArrays, int, float *, int, hipStream_t);
 hipError_t trex_launch_head(const TrexDeviceModel *, TrexBatchArrays, int, float *, hipStream_t);
 hipError_t trex_launch_link_transforms(const TrexDeviceModel *, TrexBatchArrays, int, float *, hipStream_t);
@@ -36,6 +36,10 @@ struct TrexBatch {
   TrexBatchArrays arr{};
   float wd = 1.0f, we = 0.005f, wk = 0.002f;  // trex_env.py:42-44
   std::vector<void *> allocs;
+  // caller buffers already validated as memory of this device (base address -> bytes known to be good):
+  // the hot path pays one hash-free scan of a handful of entries, hipPointerGetAttributes only on a new one
+  struct Seen { const void *p; size_t bytes; };
+  std::vector<Seen> seen;
 };
 
 namespace {
@@ -135,11 +139,54 @@ void fill_device_model(const trex::HostModel &h, TrexDeviceModel &d) {
 
 int check_batch(const TrexBatch *b) { return b ? TREX_OK : fail(TREX_E_INVALID, "null batch"); }
 
+// A caller-owned buffer must be HIP device (or managed) memory of the batch's device and at least `bytes`
+// long: a host pointer or a short buffer would make the kernel fault the GPU. NULL is accepted where the
+// header says nullable (the caller checks non-nullable arguments first).
+int check_device_buffer(TrexBatch *b, const void *p, size_t bytes, const char *what) {
+  if (!p) return TREX_OK;
+  for (const auto &s : b->seen)
+    if (s.p == p && s.bytes >= bytes) return TREX_OK;
+  hipPointerAttribute_t at;
+  std::memset(&at, 0, sizeof at);
+  hipError_t e = hipPointerGetAttributes(&at, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();   // unregistered host memory reports an error: clear it
+    return fail(TREX_E_INVALID, std::string(what) + ": not a HIP device pointer (host memory?)");
+  }
+  if (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged)
+    return fail(TREX_E_INVALID, std::string(what) + ": pointer is not device memory");
+  if (at.type == hipMemoryTypeDevice && at.device != b->device)
+    return fail(TREX_E_INVALID, std::string(what) + ": buffer lives on device " + std::to_string(at.device) +
+                                    ", the batch on device " + std::to_string(b->device));
+  void *base = nullptr;
+  size_t size = 0;
+  if (hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)p) == hipSuccess && base) {
+    const size_t left = size - (size_t)((const char *)p - (const char *)base);
+    if (left < bytes)
+      return fail(TREX_E_INVALID, std::string(what) + ": buffer too small (" + std::to_string(left) + " bytes, need " +
+                                      std::to_string(bytes) + ")");
+  } else {
+    (void)hipGetLastError();
+  }
+  if (b->seen.size() >= 64) b->seen.erase(b->seen.begin());
+  b->seen.push_back({p, bytes});
+  return TREX_OK;
+}
+#define BUF_TRY(p, bytes, what)                                                  \
+  do {                                                                           \
+    if (int _c = check_device_buffer(b, (p), (size_t)(bytes), (what))) return _c; \
+  } while (0)
+
 }  // namespace
 
 extern "C" {
 
 const char *trex_last_error(void) { return g_error.c_str(); }
+
+#ifndef TREX_BUILD_ID
+#define TREX_BUILD_ID "unknown"
+#endif
+const char *trex_build_id(void) { return TREX_BUILD_ID; }
 
 int trex_model_load(const char *urdf_path, const char *collisions_dir, TrexModel **out) {
   if (!urdf_path || !out) return fail(TREX_E_INVALID, "trex_model_load: null argument");
@@ -356,7 +403,24 @@ int trex_batch_set_reward_weights(TrexBatch *b, float distance, float energy, fl
 int trex_batch_reset(TrexBatch *b, const uint8_t *mask_dev, float *obs_out_dev, void *stream) {
   if (check_batch(b)) return TREX_E_INVALID;
   DeviceGuard guard(b->device);
-  HIP_TRY(trex_launch_reset(b->dmodel, b->arr, b->n, mask_dev, obs_out_dev, b->wd, b->we, b->wk, nullptr, (hipStream_t)stream));
+  const size_t n = (size_t)b->n;
+  BUF_TRY(mask_dev, n, "trex_batch_reset: mask");
+  BUF_TRY(obs_out_dev, n * 3 * b->nj * sizeof(float), "trex_batch_reset: obs_out");
+  HIP_TRY(trex_launch_reset(b->dmodel, b->arr, b->n, mask_dev, obs_out_dev, b->wd, b->we, b->wk, nullptr,
+                            (hipStream_t)stream, 3 * b->nj));
+  return TREX_OK;
+}
+
+int trex_batch_reset_rows(TrexBatch *b, const uint8_t *mask_dev, float *rows_dev, int row_stride, void *stream) {
+  if (check_batch(b)) return TREX_E_INVALID;
+  if (!rows_dev) return fail(TREX_E_INVALID, "trex_batch_reset_rows: rows is null");
+  if (row_stride < 3 * b->nj + 2) return fail(TREX_E_INVALID, "trex_batch_reset_rows: row_stride < 3J + 2");
+  DeviceGuard guard(b->device);
+  const size_t n = (size_t)b->n;
+  BUF_TRY(mask_dev, n, "trex_batch_reset_rows: mask");
+  BUF_TRY(rows_dev, ((n - 1) * row_stride + 3 * b->nj + 2) * sizeof(float), "trex_batch_reset_rows: rows");
+  HIP_TRY(trex_launch_reset(b->dmodel, b->arr, b->n, mask_dev, rows_dev, b->wd, b->we, b->wk, nullptr,
+                            (hipStream_t)stream, row_stride));
   return TREX_OK;
 }
 
@@ -365,8 +429,30 @@ int trex_batch_step(TrexBatch *b, const float *actions_dev, float *obs_dev, floa
   if (check_batch(b)) return TREX_E_INVALID;
   if (!actions_dev) return fail(TREX_E_INVALID, "trex_batch_step: actions is null");
   DeviceGuard guard(b->device);
+  const size_t n = (size_t)b->n;
+  BUF_TRY(actions_dev, n * b->nj * sizeof(float), "trex_batch_step: actions");
+  BUF_TRY(obs_dev, n * 3 * b->nj * sizeof(float), "trex_batch_step: obs");
+  BUF_TRY(reward_dev, n * sizeof(float), "trex_batch_step: reward");
+  BUF_TRY(done_dev, n, "trex_batch_step: done");
+  BUF_TRY(penalties_dev, n * 3 * sizeof(float), "trex_batch_step: penalties");
   HIP_TRY(trex_launch_step(b->dmodel, b->arr, b->n, actions_dev, obs_dev, reward_dev, done_dev, penalties_dev, b->wd,
-                           b->we, b->wk, nullptr, (hipStream_t)stream));
+                           b->we, b->wk, nullptr, (hipStream_t)stream, nullptr, 3 * b->nj, 1));
+  return TREX_OK;
+}
+
+int trex_batch_step_rows(TrexBatch *b, const float *actions_dev, float *rows_dev, int row_stride, float *penalties_dev,
+                         void *stream) {
+  if (check_batch(b)) return TREX_E_INVALID;
+  if (!actions_dev || !rows_dev) return fail(TREX_E_INVALID, "trex_batch_step_rows: null argument");
+  if (row_stride < 3 * b->nj + 2) return fail(TREX_E_INVALID, "trex_batch_step_rows: row_stride < 3J + 2");
+  DeviceGuard guard(b->device);
+  const size_t n = (size_t)b->n;
+  BUF_TRY(actions_dev, n * b->nj * sizeof(float), "trex_batch_step_rows: actions");
+  BUF_TRY(rows_dev, ((n - 1) * row_stride + 3 * b->nj + 2) * sizeof(float), "trex_batch_step_rows: rows");
+  BUF_TRY(penalties_dev, n * 3 * sizeof(float), "trex_batch_step_rows: penalties");
+  float *rew = rows_dev + 3 * b->nj;
+  HIP_TRY(trex_launch_step(b->dmodel, b->arr, b->n, actions_dev, rows_dev, rew, nullptr, penalties_dev, b->wd, b->we,
+                           b->wk, nullptr, (hipStream_t)stream, rew + 1, row_stride, row_stride));
   return TREX_OK;
 }
 
@@ -374,8 +460,11 @@ int trex_batch_debug_step(TrexBatch *b, const float *actions_dev, float *obs_dev
   if (check_batch(b)) return TREX_E_INVALID;
   if (!actions_dev || !debug_dev) return fail(TREX_E_INVALID, "trex_batch_debug_step: null argument");
   DeviceGuard guard(b->device);
+  BUF_TRY(actions_dev, (size_t)b->n * b->nj * sizeof(float), "trex_batch_debug_step: actions");
+  BUF_TRY(obs_dev, (size_t)b->n * 3 * b->nj * sizeof(float), "trex_batch_debug_step: obs");
+  BUF_TRY(debug_dev, 4096 * sizeof(float), "trex_batch_debug_step: debug");
   HIP_TRY(trex_launch_step(b->dmodel, b->arr, b->n, actions_dev, obs_dev, nullptr, nullptr, nullptr, b->wd, b->we, b->wk,
-                           debug_dev, (hipStream_t)stream));
+                           debug_dev, (hipStream_t)stream, nullptr, 3 * b->nj, 1));
   return TREX_OK;
 }
 
@@ -383,6 +472,7 @@ int trex_batch_get_state(TrexBatch *b, float *state_dev, void *stream) {
   if (check_batch(b)) return TREX_E_INVALID;
   if (!state_dev) return fail(TREX_E_INVALID, "state is null");
   DeviceGuard guard(b->device);
+  BUF_TRY(state_dev, (size_t)b->n * (13 + 2 * b->nj) * sizeof(float), "trex_batch_get_state: state");
   HIP_TRY(trex_launch_pack_state(b->dmodel, b->arr, b->n, state_dev, 1, (hipStream_t)stream));
   return TREX_OK;
 }
@@ -390,6 +480,7 @@ int trex_batch_set_state(TrexBatch *b, const float *state_dev, void *stream) {
   if (check_batch(b)) return TREX_E_INVALID;
   if (!state_dev) return fail(TREX_E_INVALID, "state is null");
   DeviceGuard guard(b->device);
+  BUF_TRY(state_dev, (size_t)b->n * (13 + 2 * b->nj) * sizeof(float), "trex_batch_set_state: state");
   HIP_TRY(trex_launch_pack_state(b->dmodel, b->arr, b->n, const_cast<float *>(state_dev), 0, (hipStream_t)stream));
   HIP_TRY(trex_launch_fill(b->arr.tau, 0.0f, b->n * TREX_TL, (hipStream_t)stream));
   return TREX_OK;
@@ -405,6 +496,7 @@ int trex_batch_head_position(TrexBatch *b, float *out_dev, void *stream) {
   if (check_batch(b)) return TREX_E_INVALID;
   if (!out_dev) return fail(TREX_E_INVALID, "out is null");
   DeviceGuard guard(b->device);
+  BUF_TRY(out_dev, (size_t)b->n * 3 * sizeof(float), "trex_batch_head_position: out");
   HIP_TRY(trex_launch_head(b->dmodel, b->arr, b->n, out_dev, (hipStream_t)stream));
   return TREX_OK;
 }
@@ -421,6 +513,7 @@ int trex_batch_link_transforms(TrexBatch *b, float *out_dev, void *stream) {
   if (check_batch(b)) return TREX_E_INVALID;
   if (!out_dev) return fail(TREX_E_INVALID, "out is null");
   DeviceGuard guard(b->device);
+  BUF_TRY(out_dev, (size_t)b->n * b->arr.num_links * 7 * sizeof(float), "trex_batch_link_transforms: out");
   HIP_TRY(trex_launch_link_transforms(b->dmodel, b->arr, b->n, out_dev, (hipStream_t)stream));
   return TREX_OK;
 }
@@ -428,6 +521,8 @@ int trex_batch_link_transforms(TrexBatch *b, float *out_dev, void *stream) {
 int trex_batch_set_domain(TrexBatch *b, const float *mass_scale_dev, const float *friction_dev, void *stream) {
   if (check_batch(b)) return TREX_E_INVALID;
   DeviceGuard guard(b->device);
+  BUF_TRY(mass_scale_dev, (size_t)b->n * b->nb * sizeof(float), "trex_batch_set_domain: mass_scale");
+  BUF_TRY(friction_dev, (size_t)b->n * sizeof(float), "trex_batch_set_domain: friction");
   if (mass_scale_dev) HIP_TRY(trex_launch_copy_mass_scale(mass_scale_dev, b->arr.mass_scale, b->n, b->nb, (hipStream_t)stream));
   if (friction_dev) HIP_TRY(hipMemcpyAsync(b->arr.friction, friction_dev, b->n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return TREX_OK;
@@ -436,6 +531,8 @@ int trex_batch_set_domain(TrexBatch *b, const float *mass_scale_dev, const float
 int trex_batch_contact_stats(TrexBatch *b, int32_t *count_dev, float *normal_impulse_dev, void *stream) {
   if (check_batch(b)) return TREX_E_INVALID;
   DeviceGuard guard(b->device);
+  BUF_TRY(count_dev, (size_t)b->n * sizeof(int32_t), "trex_batch_contact_stats: count");
+  BUF_TRY(normal_impulse_dev, (size_t)b->n * sizeof(float), "trex_batch_contact_stats: normal_impulse");
   if (count_dev) HIP_TRY(hipMemcpyAsync(count_dev, b->arr.contact_count, b->n * sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   if (normal_impulse_dev) HIP_TRY(hipMemcpyAsync(normal_impulse_dev, b->arr.normal_impulse, b->n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return TREX_OK;
@@ -456,6 +553,10 @@ int trex_batch_time_steps(TrexBatch *b, const float *actions_dev, float *obs_dev
   if (check_batch(b)) return TREX_E_INVALID;
   if (!actions_dev || !avg_ms_out || steps <= 0) return fail(TREX_E_INVALID, "trex_batch_time_steps: bad argument");
   DeviceGuard guard(b->device);
+  BUF_TRY(actions_dev, (size_t)b->n * b->nj * sizeof(float), "trex_batch_time_steps: actions");
+  BUF_TRY(obs_dev, (size_t)b->n * 3 * b->nj * sizeof(float), "trex_batch_time_steps: obs");
+  BUF_TRY(reward_dev, (size_t)b->n * sizeof(float), "trex_batch_time_steps: reward");
+  BUF_TRY(done_dev, (size_t)b->n, "trex_batch_time_steps: done");
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
@@ -463,7 +564,7 @@ int trex_batch_time_steps(TrexBatch *b, const float *actions_dev, float *obs_dev
   HIP_TRY(hipEventRecord(e0, s));
   for (int i = 0; i < steps; i++)
     HIP_TRY(trex_launch_step(b->dmodel, b->arr, b->n, actions_dev, obs_dev, reward_dev, done_dev, nullptr, b->wd, b->we,
-                             b->wk, nullptr, s));
+                             b->wk, nullptr, s, nullptr, 3 * b->nj, 1));
   HIP_TRY(hipEventRecord(e1, s));
   HIP_TRY(hipEventSynchronize(e1));
   float ms = 0.f;

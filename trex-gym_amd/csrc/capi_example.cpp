@@ -40,6 +40,23 @@ int main(int argc, char **argv) {
   hipStream_t stream;
   hipStreamCreate(&stream);
   CHECK(trex_batch_reset(batch, nullptr, obs, stream));
+  {
+    // A host pointer or a short buffer must come back as TREX_E_INVALID (it would fault the GPU otherwise);
+    // the batch stays usable afterwards.
+    std::vector<float> host_obs(size_t(n) * 3 * J);
+    float *small = nullptr;
+    if (hipMalloc(&small, 64)) return 1;
+    const int e1 = trex_batch_step(batch, a.data(), obs, rew, done, nullptr, stream);        // host actions
+    const int e2 = trex_batch_step(batch, act, host_obs.data(), rew, done, nullptr, stream);  // host obs
+    const int e3 = trex_batch_step(batch, act, obs, small, done, nullptr, stream);            // reward buffer too short
+    const int e4 = trex_batch_step_rows(batch, act, obs, 3 * J, nullptr, stream);             // row stride < 3J + 2
+    if (e1 != TREX_E_INVALID || e2 != TREX_E_INVALID || e3 != TREX_E_INVALID || e4 != TREX_E_INVALID) {
+      std::fprintf(stderr, "bad buffers were not refused: %d %d %d %d\n", e1, e2, e3, e4);
+      return 1;
+    }
+    std::printf("bad buffers refused: %s\n", trex_last_error());
+    hipFree(small);
+  }
   for (int t = 0; t < 20; t++) CHECK(trex_batch_step(batch, act, obs, rew, done, nullptr, stream));
   hipStreamSynchronize(stream);
   auto t0 = std::chrono::steady_clock::now();

@@ -295,9 +295,11 @@ struct KernelArgs {
   TrexBatchArrays arr;
   int n_envs;
   const float *actions;   // [N, J]
-  float *obs;             // [N, 3J] nullable
-  float *reward;          // [N] nullable
+  float *obs;             // [N, 3J] nullable; row e starts at obs + e * obs_stride
+  float *reward;          // [N] nullable; element e at reward[e * scal_stride]
   uint8_t *done;          // [N] nullable
+  float *done_f;          // done as 0.0 / 1.0 at done_f[e * scal_stride] (row-block output), nullable
+  int obs_stride, scal_stride;
   float *penalties;       // [N, 3] nullable
   const uint8_t *reset_mask;  // RESET only, nullable = all
   const int32_t *perm;        // wave slot -> env id (step launches), nullable = identity
@@ -1601,13 +1603,14 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
     }
   }
   if (args.obs && is_joint) {
-    float *o = args.obs + (size_t)env * 3 * nj;
+    float *o = args.obs + (size_t)env * args.obs_stride;
     const int obs_slot = M->obs_slot[lane];
     o[obs_slot] = q; o[nj + obs_slot] = qd; o[2 * nj + obs_slot] = mtau;
   }
   if (lane == 0) {
-    if (args.reward) args.reward[env] = env_bad ? 0.f : -lift - drift - energy;
+    if (args.reward) args.reward[(size_t)env * args.scal_stride] = env_bad ? 0.f : -lift - drift - energy;
     if (args.done) args.done[env] = env_bad ? 1 : 0;  // should_terminate() is constant False, trex_env.py:183-184
+    if (args.done_f) args.done_f[(size_t)env * args.scal_stride] = env_bad ? 1.f : 0.f;
     if (args.penalties) {
       args.penalties[env * 3 + 0] = env_bad ? 0.f : lift; args.penalties[env * 3 + 1] = env_bad ? 0.f : drift;
       args.penalties[env * 3 + 2] = env_bad ? 0.f : energy;
@@ -1789,7 +1792,7 @@ extern "C" {
 
 hipError_t trex_launch_step(const TrexDeviceModel *model, TrexBatchArrays arr, int n, const float *actions,
                             float *obs, float *reward, uint8_t *done, float *penalties, float wd, float we,
-                            float wk, float *debug, hipStream_t stream) {
+                            float wk, float *debug, hipStream_t stream, float *done_f, int obs_stride, int scal_stride) {
   // diagnostics launches keep env 0 and 1 in workgroup 0
 #if TREX_STAMPS
   // diagnostic build: TREX_DEBUG_PAIR=1 keeps the pairing in debug launches (scripts/wave_balance.py)
@@ -1799,15 +1802,15 @@ hipError_t trex_launch_step(const TrexDeviceModel *model, TrexBatchArrays arr, i
   const int32_t *perm = (debug || n < 4) ? nullptr : arr.pair_perm;
 #endif
   if (perm) hipLaunchKernelGGL(trex_pair_kernel, dim3(1), dim3(1024), 0, stream, arr.contact_count, arr.pair_perm, n);
-  KernelArgs a{model, arr, n, actions, obs, reward, done, penalties, nullptr, perm, wd, we, wk, debug};
+  KernelArgs a{model, arr, n, actions, obs, reward, done, done_f, obs_stride, scal_stride, penalties, nullptr, perm, wd, we, wk, debug};
   if (debug) hipLaunchKernelGGL((trex_step_kernel<false, true>), dim3((n + 1) / 2), dim3(64), 0, stream, a);
   else hipLaunchKernelGGL((trex_step_kernel<false, false>), dim3((n + 1) / 2), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
 
 hipError_t trex_launch_reset(const TrexDeviceModel *model, TrexBatchArrays arr, int n, const uint8_t *mask,
-                             float *obs, float wd, float we, float wk, float *debug, hipStream_t stream) {
-  KernelArgs a{model, arr, n, nullptr, obs, nullptr, nullptr, nullptr, mask, nullptr, wd, we, wk, debug};
+                             float *obs, float wd, float we, float wk, float *debug, hipStream_t stream, int obs_stride) {
+  KernelArgs a{model, arr, n, nullptr, obs, nullptr, nullptr, nullptr, obs_stride, 1, nullptr, mask, nullptr, wd, we, wk, debug};
   hipLaunchKernelGGL((trex_step_kernel<true, false>), dim3((n + 1) / 2), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
@@ -1819,13 +1822,13 @@ hipError_t trex_launch_pack_state(const TrexDeviceModel *model, TrexBatchArrays 
 }
 
 hipError_t trex_launch_head(const TrexDeviceModel *model, TrexBatchArrays arr, int n, float *out, hipStream_t stream) {
-  KernelArgs a{model, arr, n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, nullptr};
+  KernelArgs a{model, arr, n, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, nullptr};
   hipLaunchKernelGGL(trex_head_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a, out);
   return hipGetLastError();
 }
 
 hipError_t trex_launch_link_transforms(const TrexDeviceModel *model, TrexBatchArrays arr, int n, float *out, hipStream_t stream) {
-  KernelArgs a{model, arr, n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, nullptr};
+  KernelArgs a{model, arr, n, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, nullptr};
   hipLaunchKernelGGL(trex_link_transforms_kernel, dim3(n), dim3(64), 0, stream, a, out);
   return hipGetLastError();
 }

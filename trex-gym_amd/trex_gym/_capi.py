@@ -36,10 +36,12 @@ SYMBOLS = [
     "trex_batch_contact_stats", "trex_batch_debug_step", "trex_batch_launch_info", "trex_batch_time_steps",
     "trex_model_num_links", "trex_model_link_info", "trex_batch_link_transforms",
     "trex_model_use_primitive_collision", "trex_model_fit_hull_primitives",
+    "trex_build_id", "trex_batch_step_rows", "trex_batch_reset_rows",
 ]
 
 _vp = C.c_void_p
 lib.trex_last_error.restype = C.c_char_p
+lib.trex_build_id.restype = C.c_char_p
 lib.trex_model_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(_vp)]
 lib.trex_model_destroy.argtypes = [_vp]
 lib.trex_model_destroy.restype = None
@@ -62,6 +64,8 @@ lib.trex_batch_num_envs.argtypes = [_vp]
 lib.trex_batch_set_reward_weights.argtypes = [_vp, C.c_float, C.c_float, C.c_float]
 lib.trex_batch_reset.argtypes = [_vp, _vp, _vp, _vp]
 lib.trex_batch_step.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp]
+lib.trex_batch_step_rows.argtypes = [_vp, _vp, _vp, C.c_int, _vp, _vp]
+lib.trex_batch_reset_rows.argtypes = [_vp, _vp, _vp, C.c_int, _vp]
 lib.trex_batch_debug_step.argtypes = [_vp, _vp, _vp, _vp, _vp]
 lib.trex_batch_get_state.argtypes = [_vp, _vp, _vp]
 lib.trex_batch_set_state.argtypes = [_vp, _vp, _vp]
@@ -92,15 +96,29 @@ def check(code):
     return code
 
 
-def _ptr(t):
-    """torch tensor / None -> void* (device pointer). A host tensor here would make the kernel fault the
-    GPU, so it is refused."""
+E_INVALID = -1   # TREX_E_INVALID
+
+
+def build_id():
+    return lib.trex_build_id().decode()
+
+
+def _ptr(t, device=None, dtype=None, numel=None, what="tensor"):
+    """torch tensor / None -> void* (device pointer). A host tensor, a tensor on another GPU, of another
+    dtype or too short would be misread or fault the GPU, so it is refused here (TREX_E_INVALID); the
+    C-ABI checks the raw pointer again (capi.cpp check_device_buffer)."""
     if t is None:
         return None
     if not t.is_cuda:
-        raise TrexError(-2, "expected a tensor in device memory, got one on %s" % t.device)
+        raise TrexError(E_INVALID, "%s: expected a tensor in device memory, got one on %s" % (what, t.device))
     if not t.is_contiguous():
-        raise TrexError(-2, "expected a contiguous tensor")
+        raise TrexError(E_INVALID, "%s: expected a contiguous tensor" % what)
+    if device is not None and t.device.index != device:
+        raise TrexError(E_INVALID, "%s: tensor on cuda:%s, batch on cuda:%d" % (what, t.device.index, device))
+    if dtype is not None and t.dtype != dtype:
+        raise TrexError(E_INVALID, "%s: expected dtype %s, got %s" % (what, dtype, t.dtype))
+    if numel is not None and t.numel() < numel:
+        raise TrexError(E_INVALID, "%s: expected at least %d elements, got %d" % (what, numel, t.numel()))
     return C.c_void_p(t.data_ptr())
 
 
@@ -220,36 +238,66 @@ class Batch:
     def set_reward_weights(self, distance, energy, drift):
         check(lib.trex_batch_set_reward_weights(self.h, distance, energy, drift))
 
+    def _p(self, t, dtype, numel, what):
+        import torch
+        return _ptr(t, self.device, getattr(torch, dtype), numel, what)
+
     def reset(self, obs_out=None, mask=None, stream=None):
-        check(lib.trex_batch_reset(self.h, _ptr(mask), _ptr(obs_out), self._stream(stream)))
+        n, J = self.num_envs, self.J
+        check(lib.trex_batch_reset(self.h, self._p(mask, "uint8", n, "mask"), self._p(obs_out, "float32", n * 3 * J, "obs_out"),
+                                   self._stream(stream)))
 
     def step(self, actions, obs, reward, done, penalties=None, stream=None):
-        check(lib.trex_batch_step(self.h, _ptr(actions), _ptr(obs), _ptr(reward), _ptr(done), _ptr(penalties),
-                                  self._stream(stream)))
+        n, J = self.num_envs, self.J
+        check(lib.trex_batch_step(self.h, self._p(actions, "float32", n * J, "actions"), self._p(obs, "float32", n * 3 * J, "obs"),
+                                  self._p(reward, "float32", n, "reward"), self._p(done, "uint8", n, "done"),
+                                  self._p(penalties, "float32", 3 * n, "penalties"), self._stream(stream)))
+
+    def step_rows(self, actions, rows, penalties=None, stream=None):
+        """One step writing the [n, stride] row block obs | reward | done (stride = rows.shape[1] >= 3J + 2)."""
+        n, J = self.num_envs, self.J
+        check(lib.trex_batch_step_rows(self.h, self._p(actions, "float32", n * J, "actions"),
+                                       self._p(rows, "float32", n * (3 * J + 2), "rows"), int(rows.shape[1]),
+                                       self._p(penalties, "float32", 3 * n, "penalties"), self._stream(stream)))
+
+    def reset_rows(self, rows, mask=None, stream=None):
+        n, J = self.num_envs, self.J
+        check(lib.trex_batch_reset_rows(self.h, self._p(mask, "uint8", n, "mask"),
+                                        self._p(rows, "float32", n * (3 * J + 2), "rows"), int(rows.shape[1]),
+                                        self._stream(stream)))
 
     def debug_step(self, actions, obs, debug, stream=None):
-        check(lib.trex_batch_debug_step(self.h, _ptr(actions), _ptr(obs), _ptr(debug), self._stream(stream)))
+        n, J = self.num_envs, self.J
+        check(lib.trex_batch_debug_step(self.h, self._p(actions, "float32", n * J, "actions"),
+                                        self._p(obs, "float32", n * 3 * J, "obs"), self._p(debug, "float32", 4096, "debug"),
+                                        self._stream(stream)))
 
     def get_state(self, out, stream=None):
-        check(lib.trex_batch_get_state(self.h, _ptr(out), self._stream(stream)))
+        check(lib.trex_batch_get_state(self.h, self._p(out, "float32", self.num_envs * self.state_width, "state"),
+                                       self._stream(stream)))
 
     def set_state(self, state, stream=None):
-        check(lib.trex_batch_set_state(self.h, _ptr(state), self._stream(stream)))
+        check(lib.trex_batch_set_state(self.h, self._p(state, "float32", self.num_envs * self.state_width, "state"),
+                                       self._stream(stream)))
 
     def set_motors_enabled(self, enabled, stream=None):
         check(lib.trex_batch_set_motors_enabled(self.h, int(enabled), self._stream(stream)))
 
     def head_position(self, out, stream=None):
-        check(lib.trex_batch_head_position(self.h, _ptr(out), self._stream(stream)))
+        check(lib.trex_batch_head_position(self.h, self._p(out, "float32", 3 * self.num_envs, "out"), self._stream(stream)))
 
     def link_transforms(self, out, stream=None):
-        check(lib.trex_batch_link_transforms(self.h, _ptr(out), self._stream(stream)))
+        check(lib.trex_batch_link_transforms(self.h, self._p(out, "float32", None, "out"), self._stream(stream)))
 
     def set_domain(self, mass_scale=None, friction=None, stream=None):
-        check(lib.trex_batch_set_domain(self.h, _ptr(mass_scale), _ptr(friction), self._stream(stream)))
+        n = self.num_envs
+        check(lib.trex_batch_set_domain(self.h, self._p(mass_scale, "float32", n * self.model.num_bodies, "mass_scale"),
+                                        self._p(friction, "float32", n, "friction"), self._stream(stream)))
 
     def contact_stats(self, count=None, normal_impulse=None, stream=None):
-        check(lib.trex_batch_contact_stats(self.h, _ptr(count), _ptr(normal_impulse), self._stream(stream)))
+        n = self.num_envs
+        check(lib.trex_batch_contact_stats(self.h, self._p(count, "int32", n, "count"),
+                                           self._p(normal_impulse, "float32", n, "normal_impulse"), self._stream(stream)))
 
     def launch_info(self):
         g, b, l, a = C.c_int(), C.c_int(), C.c_int(), C.c_int()
@@ -258,6 +306,8 @@ class Batch:
 
     def time_steps(self, actions, obs, reward, done, steps, stream=None):
         ms = C.c_float()
-        check(lib.trex_batch_time_steps(self.h, _ptr(actions), _ptr(obs), _ptr(reward), _ptr(done), int(steps),
+        n, J = self.num_envs, self.J
+        check(lib.trex_batch_time_steps(self.h, self._p(actions, "float32", n * J, "actions"), self._p(obs, "float32", n * 3 * J, "obs"),
+                                        self._p(reward, "float32", n, "reward"), self._p(done, "uint8", n, "done"), int(steps),
                                         self._stream(stream), C.byref(ms)))
         return ms.value

@@ -2,7 +2,7 @@
 
 Envs are independent (the reference runs a single env, trex_train.py:44), so the batch shards by
 contiguous env-id ranges with no data-path collective. The only exchange is the all-gather of the
-observation rows when a centralised consumer wants the whole batch: `all_gather_rows`
+[obs | reward | done] row block when a centralised consumer wants the whole batch: `all_gather_rows`
 (torch.distributed.all_gather_into_tensor: RCCL over xGMI with backend "nccl" on ROCm, gloo in the
 CPU tests). Device-agnostic on purpose: nothing here touches HIP.
 """
@@ -36,6 +36,25 @@ def synthetic_actions(env_ids, step, low, high, seed=0, device="cpu"):
         x = x ^ (x >> sh)
     u = (x & ((1 << 24) - 1)).to(torch.float32) / float(1 << 24)
     return low + (high - low) * u
+
+
+def pack_rows(obs, reward, done, out=None):
+    """[n, 3J] obs, [n] reward, [n] done (any dtype) -> the [n, 3J+2] f32 row block the exchange carries
+    (obs + reward + done in one message). The HIP step writes this layout directly
+    (trex_batch_step_rows); this is the host-side / CPU-test equivalent."""
+    n, c = obs.shape
+    if out is None:
+        out = torch.empty(n, c + 2, dtype=torch.float32, device=obs.device)
+    out[:, :c] = obs
+    out[:, c] = reward
+    out[:, c + 1] = done.to(torch.float32)
+    return out
+
+
+def split_rows(rows):
+    """[N, 3J+2] row block -> (obs [N, 3J], reward [N], done [N] bool) views."""
+    c = rows.shape[1] - 2
+    return rows[:, :c], rows[:, c], rows[:, c + 1] != 0
 
 
 def all_gather_rows(local, global_rows, world_size, group=None, out=None):

@@ -8,8 +8,11 @@ step_async(), step_wait(), step(), close(); plus tensor-native variants that kee
 (should_terminate() is constant False, trex_env.py:183-184); a time limit, if any, is the
 harness's: `max_episode_steps` (None = never) auto-resets like a VecEnv does and reports done=True.
 
+Outputs live in ONE row block `rows` [n, 3J+2] f32 = obs | reward | done (written by the kernel in that
+layout: trex_batch_step_rows); `obs`, `rew` and `done_f` are views into it.
+
 Multi-GPU: one process per GPU, env ids sharded by contiguous range (trex_gym.sharding); the only
-exchange is the all-gather of the observation rows (all_gather_obs).
+exchange is the all-gather of that row block (all_gather_rows / all_gather_rows_pipelined).
 """
 import numpy as np
 import torch
@@ -36,6 +39,8 @@ class TrexVecEnv:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _capi.TrexError(-5, "TrexVecEnv needs a HIP device; the physics step has no CPU fallback")
+        if self.device.index is None:   # "cuda" without an index means the CURRENT device, for batch and buffers alike
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.model = _capi.Model(urdf_path, collisions_dir)
         # NUM_SUBSTEPS = 5 physics substeps per action repeat (trex_env.py:18,71-73)
         self.model.set_param("substeps", 5 * int(action_repeat))
@@ -47,7 +52,7 @@ class TrexVecEnv:
             raise ValueError("collision must be 'hulls' or 'primitives'")
         for name, angle in (starting_configuration or {}).items():
             self.model.set_start_angle(name, angle)  # unknown name raises, like KeyError at trex_robot.py:307
-        self.batch = _capi.Batch(self.model, self.num_envs, self.device.index or 0)
+        self.batch = _capi.Batch(self.model, self.num_envs, self.device.index)
         self.batch.set_reward_weights(distance_weight, energy_weight, drift_weight)
         J = self.J = self.model.num_joints
         lo, hi = self.model.lower.astype(np.float32), self.model.upper.astype(np.float32)
@@ -56,9 +61,10 @@ class TrexVecEnv:
         self.observation_space = spaces.Box(low=np.concatenate([lo, -big]), high=np.concatenate([hi, big]),
                                             dtype=np.float32)
         n = self.num_envs
-        self.obs = torch.zeros(n, 3 * J, device=self.device)
-        self.rew = torch.zeros(n, device=self.device)
-        self.done = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        self.rows = torch.zeros(n, 3 * J + 2, device=self.device)   # obs | reward | done
+        self.obs = self.rows[:, :3 * J]
+        self.rew = self.rows[:, 3 * J]
+        self.done_f = self.rows[:, 3 * J + 1]
         self.penalties = torch.zeros(n, 3, device=self.device)
         self.episode_steps = torch.zeros(n, dtype=torch.int32, device=self.device)
         self.max_episode_steps = max_episode_steps
@@ -69,7 +75,7 @@ class TrexVecEnv:
     # ---- tensor-native API (stays on device, stream-ordered, no host sync)
     def reset_tensor(self, mask=None):
         """Reset all envs (mask=None) or those with mask != 0 (uint8 [n]). Returns obs [n, 3J]."""
-        self.batch.reset(self.obs, mask)
+        self.batch.reset_rows(self.rows, mask)
         if mask is None:
             self.episode_steps.zero_()
         else:
@@ -83,39 +89,44 @@ class TrexVecEnv:
             actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
         if tuple(actions.shape) != (self.num_envs, self.J):
             raise ValueError("actions must have shape (%d, %d), got %s" % (self.num_envs, self.J, tuple(actions.shape)))
-        self.batch.step(actions, self.obs, self.rew, self.done, self.penalties)
-        done = self.done.bool()
+        self.batch.step_rows(actions, self.rows, self.penalties)
+        done = self.done_f != 0
         if self.max_episode_steps is not None:
             # VecEnv auto-reset without a host sync: the masked reset kernel is launched every step
-            # (teams whose mask is 0 skip the physics) and obs becomes that of the new episode.
+            # (waves whose mask is 0 skip the physics) and obs becomes that of the new episode.
             self.episode_steps += 1
             done = done | (self.episode_steps >= self.max_episode_steps)   # time limit, or a contained non-finite env
-            self.batch.reset(self.obs, done.to(torch.uint8))
+            self.done_f.copy_(done)          # the gathered row block carries the harness's done too
+            self.batch.reset_rows(self.rows, done.to(torch.uint8))
             self.episode_steps.masked_fill_(done, 0)
         return self.obs, self.rew, done
 
-    def all_gather_obs(self, obs=None):
-        """[global N, 3J] on every rank: the one collective of the path (RCCL all-gather over xGMI;
-        gloo in the CPU tests)."""
-        obs = self.obs if obs is None else obs
+    def all_gather_rows(self, rows=None):
+        """[global N, 3J+2] = obs | reward | done of EVERY env, on every rank: the one collective of the path
+        (RCCL all-gather over xGMI; gloo in the CPU tests). sharding.split_rows() cuts it back into the three."""
+        rows = self.rows if rows is None else rows
         if self.world_size == 1:
-            return obs
-        self._gather_buf = sharding.all_gather_rows(obs, self.global_num_envs, self.world_size,
+            return rows
+        self._gather_buf = sharding.all_gather_rows(rows, self.global_num_envs, self.world_size,
                                                     self.process_group, out=self._gather_buf)
         return self._gather_buf
 
-    def all_gather_obs_pipelined(self, obs=None):
-        """Like all_gather_obs, but the collective overlaps the next step: returns the rows gathered by the
+    def all_gather_rows_pipelined(self, rows=None):
+        """Like all_gather_rows, but the collective overlaps the next step: returns the rows gathered by the
         PREVIOUS call (None on the first). See sharding.PipelinedGather."""
-        obs = self.obs if obs is None else obs
+        rows = self.rows if rows is None else rows
         if self.world_size == 1:
-            return obs
+            return rows
         if self._pipe is None:
             if self.global_num_envs != self.num_envs * self.world_size:
                 raise ValueError("pipelined gather needs equal shards")
-            self._pipe = sharding.PipelinedGather(self.num_envs, obs.shape[1], self.world_size, obs.dtype,
+            self._pipe = sharding.PipelinedGather(self.num_envs, rows.shape[1], self.world_size, rows.dtype,
                                                   self.device, self.process_group)
-        return self._pipe.push(obs)
+        return self._pipe.push(rows)
+
+    def all_gather_obs(self):
+        """[global N, 3J]: the observation columns of all_gather_rows()."""
+        return self.all_gather_rows()[:, :3 * self.J]
 
     # ---- baselines VecEnv API (host numpy in/out)
     def reset(self):
