@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Per-wave phase cycles of the one-env-per-wave step kernel in the bench.py state mix (DIAGNOSTIC build:
+make -C trex-gym_amd/csrc stamps_w1 / stamps; TREX_LIB selects it). Every wave accumulates s_memtime deltas
+per phase over the 5 substeps of ONE launch; the script prints the mean per phase, the same for the slowest
+waves, and wave time against contact count. Shares, not lengths, are meaningful (the stamps fence the
+scheduler and add global read-modify-writes)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(ROOT, "trex-gym_amd"))
+from trex_gym import _capi, sharding  # noqa: E402
+
+NAMES = ["FK", "contact generation", "velocities, inertia, bias", "ABA pass 2 (LDS)", "base inverse, pass 3, vel update",
+         "row walks", "z0 stash + B build", "PGS sweeps", "results + integrate"]
+
+
+def main():
+    dev = torch.device("cuda:0")
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    pre = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+    m = _capi.Model()
+    b = _capi.Batch(m, n)
+    obs = torch.zeros(n, 75, device=dev); rew = torch.zeros(n, device=dev); done = torch.zeros(n, dtype=torch.uint8, device=dev)
+    ids = torch.arange(n, device=dev)
+    lo, hi = torch.tensor(m.lower, dtype=torch.float32, device=dev), torch.tensor(m.upper, dtype=torch.float32, device=dev)
+    # staggered episodes like bench.py: env i is reset when (t + phase_i) % 1000 == 0
+    phase = (ids * 1000) // n
+    b.reset(obs)
+    for t in range(pre):
+        b.step(sharding.synthetic_actions(ids, t, lo, hi, seed=0, device=dev), obs, rew, done)
+        mk = (phase == ((-(t + 1)) % 1000)).to(torch.uint8)
+        if bool(mk.any()):
+            b.reset(obs, mk)
+    dbg = torch.zeros(4096 + 16 * n, device=dev)
+    b.debug_step(sharding.synthetic_actions(ids, pre, lo, hi, seed=0, device=dev), obs, dbg)
+    torch.cuda.synchronize()
+    cnt = torch.zeros(n, dtype=torch.int32, device=dev)
+    b.contact_stats(cnt, None)
+    c = cnt.cpu().numpy()
+    d = dbg.cpu().numpy()[4096:4096 + 9 * n].reshape(9, n)
+    tot = d.sum(0)
+    print("waves %d, contacts per env mean %.2f max %d" % (n, c.mean(), c.max()))
+    print("wave cycles: mean %.3g  median %.3g  p90 %.3g  p99 %.3g  max %.3g  (max/mean %.2f)" % (
+        tot.mean(), np.median(tot), np.percentile(tot, 90), np.percentile(tot, 99), tot.max(), tot.max() / tot.mean()))
+    slow = np.argsort(tot)[-max(1, n // 100):]
+    print("%-36s %12s %7s %14s" % ("phase", "mean cycles", "share", "slowest 1 %"))
+    for k, name in enumerate(NAMES):
+        print("%-36s %12.0f %6.1f %% %14.0f" % (name, d[k].mean(), 100 * d[k].mean() / tot.mean(), d[k][slow].mean()))
+    for lo_, hi_ in ((0, 0), (1, 4), (5, 8), (9, 13)):
+        sel = (c >= lo_) & (c <= hi_)
+        if sel.any():
+            rows = 25 + 3 * c[sel].mean()
+            print("envs with %2d..%2d contacts: %5d  wave cycles mean %.3g max %.3g; sweeps mean %.3g = %.1f cycles per row visit" % (
+                lo_, hi_, sel.sum(), tot[sel].mean(), tot[sel].max(), d[7][sel].mean(), d[7][sel].mean() / (300 * rows)))
+
+
+if __name__ == "__main__":
+    main()

@@ -33,10 +33,10 @@ def make_vec(n, **kw):
     return TrexVecEnv(n, urdf_path=ASSET_URDF, device=DEV, **kw)
 
 
-def assert_step_close(g_obs, o_obs, g_rew=None, o_rew=None, what=""):
+def assert_step_close(g_obs, o_obs, g_rew=None, o_rew=None, what="", q_atol=1e-4):
     J = 25
     assert np.isfinite(g_obs).all(), what
-    np.testing.assert_allclose(g_obs[:J], o_obs[:J], atol=1e-4, rtol=0, err_msg=what + " q")
+    np.testing.assert_allclose(g_obs[:J], o_obs[:J], atol=q_atol, rtol=0, err_msg=what + " q")
     np.testing.assert_allclose(g_obs[J:2 * J], o_obs[J:2 * J], atol=5e-3 * max(1.0, np.abs(o_obs[J:2 * J]).max()),
                                rtol=0, err_msg=what + " qd")
     np.testing.assert_allclose(g_obs[2 * J:], o_obs[2 * J:], atol=5e-3 * np.abs(o_obs[2 * J:]).max() + 1.0, rtol=0,
@@ -274,9 +274,10 @@ def test_full_envs_are_independent_and_deterministic(full):
     assert o1.std(0).max() > 0                                 # envs really differ
 
 
-def test_wave_pairing_and_contact_budget(full):
-    """The launch pairs envs by their previous contact count (lightest with heaviest); an env's results
-    must not depend on its history-dependent partner. And the contact budget: never more than 13 points."""
+def test_wave_balance_and_contact_budget(full):
+    """The launch ranks envs by their previous contact count and deals the ranks over the SIMDs (balance
+    kernel); an env's results must not depend on its history-dependent slot. And the contact budget: never
+    more than 13 points."""
     v, lo, hi = full
     g = torch.Generator(device=DEV).manual_seed(7)
     v.reset_tensor()
@@ -289,7 +290,7 @@ def test_wave_pairing_and_contact_budget(full):
     a = (lo + (hi - lo) * torch.rand(N_FULL, 25, device=DEV, generator=g)).contiguous()
     o1, r1, _ = v.step_tensor(a)
     o1, r1, s1 = o1.clone(), r1.clone(), v.get_state()
-    # same states, but the stored contact counts (hence the pairing) come from a different history
+    # same states, but the stored contact counts (hence the slot of every env) come from a different history
     v.reset_tensor()
     v.step_tensor(a)
     v.set_state(st)
@@ -399,7 +400,12 @@ def test_config4_size_on_one_gpu(oracle64, model):
         s = oracle64.new_state()
         oracle64.set_state(s, st_h[e].astype(np.float64))
         o, r, _ = oracle64.step(s, a_h[e].astype(np.float64))
-        assert_step_close(o_h[e], o, r_h[e], r, "config-4 env %d (%d contacts)" % (e, c_h[e]))
+        # These are the wildest states of the suite (60 random-action steps, up to 13 contact points, joint
+        # rates of tens of rad/s). The angle error is the time integral of the rate error over the env-step
+        # (5 x 0.002 s), so its bound is derived from the stated rate tolerance, not fitted:
+        #   |dq| <= 1e-4 + 0.01 s * 5e-3 * max(1, |qd|_inf)
+        qtol = 1e-4 + 0.01 * 5e-3 * max(1.0, np.abs(o[25:50]).max())
+        assert_step_close(o_h[e], o, r_h[e], r, "config-4 env %d (%d contacts)" % (e, c_h[e]), q_atol=qtol)
         assert len(oracle64.contacts(s)[0]) == c_h[e]
 
 
@@ -425,8 +431,7 @@ def test_time_limit_auto_reset():
 
 
 def test_non_finite_env_is_contained():
-    """A NaN / Inf state resets that env (done = 1, reward 0) and leaves every other env - including
-    its wave partner - bitwise untouched."""
+    """A NaN / Inf state resets that env (done = 1, reward 0) and leaves every other env bitwise untouched."""
     v = make_vec(6)
     v.reset()
     a = torch.zeros(6, 25, device=DEV)
@@ -437,7 +442,7 @@ def test_non_finite_env_is_contained():
     ref.reset()
     ref.set_state(st)
     bad = st.clone()
-    bad[2, 40] = float("nan")      # env 2 shares a wave with env 3
+    bad[2, 40] = float("nan")
     bad[5, 2] = float("inf")
     v.set_state(bad)
     o1, r1, d1 = v.step_tensor(a)

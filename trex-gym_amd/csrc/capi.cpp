@@ -24,6 +24,7 @@ hipError_t trex_launch_fill(float *, float, int, hipStream_t);
 hipError_t trex_launch_fill_u8(uint8_t *, uint8_t, int, hipStream_t);
 hipError_t trex_launch_copy_mass_scale(const float *, float *, int, int, hipStream_t);
 int trex_step_lds_bytes(void);
+int trex_step_envs_per_workgroup(void);
 }
 
 struct TrexModel {
@@ -81,6 +82,9 @@ void fill_device_model(const trex::HostModel &h, TrexDeviceModel &d) {
                                 p.floor_z, p.friction, p.erp, p.contact_erp, p.contact_margin, p.link_damping,
                                 p.max_coordinate_velocity, p.max_contacts};
   for (int i = 0; i < TP_COUNT; i++) d.prm[i] = (float)prm[i];
+  d.n_substeps = (int)p.substeps; d.n_iterations = (int)p.iterations; d.max_contacts = (int)p.max_contacts;
+  d.inv_dt = 1.0f / (float)p.dt;
+  d.motor_max_impulse = (float)p.motor_max_force * (float)p.dt;
   d.head_point[0] = (float)h.head_point.x; d.head_point[1] = (float)h.head_point.y; d.head_point[2] = (float)h.head_point.z;
   d.base_pos0[0] = (float)h.base_start_pos.x; d.base_pos0[1] = (float)h.base_start_pos.y; d.base_pos0[2] = (float)h.base_start_pos.z;
   for (int c = 0; c < 4; c++) d.base_quat0[c] = (float)h.base_start_quat[c];
@@ -462,7 +466,7 @@ int trex_batch_debug_step(TrexBatch *b, const float *actions_dev, float *obs_dev
   DeviceGuard guard(b->device);
   BUF_TRY(actions_dev, (size_t)b->n * b->nj * sizeof(float), "trex_batch_debug_step: actions");
   BUF_TRY(obs_dev, (size_t)b->n * 3 * b->nj * sizeof(float), "trex_batch_debug_step: obs");
-  BUF_TRY(debug_dev, 4096 * sizeof(float), "trex_batch_debug_step: debug");
+  BUF_TRY(debug_dev, 4096 * sizeof(float), "trex_batch_debug_step: debug");   // (diagnostic builds: 4096 + 16 N)
   HIP_TRY(trex_launch_step(b->dmodel, b->arr, b->n, actions_dev, obs_dev, nullptr, nullptr, nullptr, b->wd, b->we, b->wk,
                            debug_dev, (hipStream_t)stream, nullptr, 3 * b->nj, 1));
   return TREX_OK;
@@ -540,7 +544,8 @@ int trex_batch_contact_stats(TrexBatch *b, int32_t *count_dev, float *normal_imp
 
 int trex_batch_launch_info(const TrexBatch *b, int *grid, int *block, int *lds_bytes, int *alg_bytes_per_env_step) {
   if (!b) return fail(TREX_E_INVALID, "null batch");
-  if (grid) *grid = (b->n + 1) / 2;
+  const int epw = trex_step_envs_per_workgroup();
+  if (grid) *grid = (b->n + epw - 1) / epw;
   if (block) *block = 64;
   if (lds_bytes) *lds_bytes = trex_step_lds_bytes();
   // state in + out (13 + 2J floats each), action in (J), obs out (3J), reward (4 B), done (padded 4 B): SURVEY 8d

@@ -18,6 +18,10 @@ enum TrexParam {
 struct TrexDeviceModel {
   int nb, maxdepth, head_body, nv;
   float prm[16];
+  /* the same, ready for scalar loads: integer parameters as integers and the derived constants, so that no
+   * wave-uniform conversion / division is done (and kept) in vector registers */
+  int n_substeps, n_iterations, max_contacts, pad0;
+  float inv_dt, motor_max_impulse, pad1, pad2;
   float head_point[4];
   float base_pos0[4], base_quat0[4];
   int parent[TREX_TL], depth[TREX_TL];

@@ -6,24 +6,30 @@
 // (trex_env.py:186-196); with RESET: TrexBulletEnv.reset() (trex_env.py:98-122).
 //
 // Mapping to the hardware
-//   * one 64-lane wavefront = one workgroup = TWO envs. Tree phases: one env per 32-lane half ("team"):
-//     the tree has 26 bodies and 25 + 6 = 31 degrees of freedom, so a team's lanes are the bodies 0..25
-//     (lanes 1..25 = joint of that body, lanes 26..31 = base angular xyz / linear xyz for the
-//     factorisation). Constraint solve: one env at a time on all 64 lanes, ONE CONSTRAINT ROW PER LANE
-//     (25 motor rows + 3 x 13 contact rows = 64).  No inter-wave synchronisation exists.
+//   * ONE ENV PER 64-LANE WAVEFRONT, one wavefront per workgroup, at most 128 registers per lane and
+//     10 KB of LDS per workgroup: 4 waves per SIMD (16 per CU), so that at the headline 4096 envs every
+//     env is resident at once (4096 waves = 1024 SIMDs x 4) and the serial Gauss-Seidel chain of one env
+//     hides behind the three other waves of its SIMD. No inter-wave synchronisation exists.
+//   * lanes 0..25 = the 26 bodies (lane b = body b = joint b) for the tree sweeps; for the constraint
+//     solve ONE CONSTRAINT ROW PER LANE: motor row j (with joint j's limit row riding on it) on lane j
+//     (1..25), the 3 x 13 contact rows on lanes 26..63 and 0.
 //   * every spatial quantity is expressed in WORLD-ALIGNED axes about the body's OWN frame origin
 //     (the joint axis passes through it). Parent<->child sweeps therefore need no rotations - only
-//     the translation by the joint offset d - and, unlike a single common origin, no quantity is a
-//     difference of m*r^2-sized terms (f32-safe: D_i = a.(I a) directly). Base-to-tip passes move
-//     6..12 registers per level with wavefront shuffles (ds_bpermute within the half), the
-//     tip-to-base articulated-inertia pass stages 27 floats per body through LDS.
+//     the translation by the joint offset d - and no quantity is a difference of m*r^2-sized terms
+//     (f32-safe: D_i = a.(I a) directly). Base-to-tip passes move 6..12 registers per level with
+//     wavefront shuffles, the tip-to-base articulated-inertia pass stages 27 floats per body through LDS.
+//   * the env's base state (pose, twist) is wave-uniform and lives in SGPRs; what later phases need of a
+//     body (axis, origin, U/D, 1/D, updated joint rate, parent) is PARKED in LDS as one 80-byte record
+//     per body instead of being carried in registers across phases.
 //   * M^-1 is never formed by repeated sweeps: the ABA factorisation M^-1 = A^T B A is kept
-//     DISTRIBUTED (lane j holds column j of A: <= 6 ancestor entries + 6 base entries); any entry of
-//     the Delassus matrix J M^-1 J^T is then 12 multiply-adds of two row descriptors.
+//     DISTRIBUTED. Every constraint row walks ITS OWN chain once, on its own lane (motor rows and
+//     contact rows in the same pass, reading the body records), and keeps a descriptor (chain nodes,
+//     entries u, u/D, base force r0, I0^-1 r0); any entry of the Delassus matrix J M^-1 J^T is then 12
+//     multiply-adds of two descriptors, the column's one broadcast with v_readlane.
 //   * projected Gauss-Seidel runs in Delassus (residual) form: a row's impulse change reaches all other
 //     rows as one v_readlane (SGPR broadcast) + one FMA per lane - no reduction, no LDS in a row.
 //   * HBM traffic per env-step is the state row in/out + action in + obs/reward out (912 B); the
-//     kernel is bound by the instruction issue of its heaviest wave, not by bandwidth.
+//     kernel is bound by VALU issue, not by bandwidth.
 //
 // The arithmetic is the one restated by oracle/trex_oracle.c; tests/ compare the two.
 #include <hip/hip_runtime.h>
@@ -44,97 +50,86 @@
 #define TREX_STAMPS 0
 #endif
 #ifndef TREX_PRIO_MODE
-#define TREX_PRIO_MODE 2   // 0 none, 1 per-env priority during its sweeps, 2 per-wave priority from contact generation on
+#define TREX_PRIO_MODE 1   // 0 none, 1 by contact count during the sweeps only, 2 for the whole substep
 #endif
-// Diagnostic build only (make stamps): s_memtime at phase boundaries of workgroup 0, written to the
-// debug buffer at [3000 + 16*substep + phase] as cycle deltas. Never compiled into the product library.
+// Diagnostic build only (make stamps): s_memtime at phase boundaries of workgroup 0, accumulated into the
+// debug buffer at [3000 + phase] as cycles. Never compiled into the product library.
 #if TREX_STAMPS
+// per-wave phase cycles: debug[4096 + phase * n_envs + wave] accumulates over the substeps of the launch
 #define STAMP(i)                                                                          \
   do {                                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                    \
     const unsigned long long _t = __builtin_amdgcn_s_memtime();                           \
     __builtin_amdgcn_s_waitcnt(0xC07F);                                                   \
-    if (DEBUG && args.debug && blockIdx.x == 0 && threadIdx.x == 0) args.debug[3000 + 16 * sub + (i)] += (float)(_t - stamp_last); \
+    if (DEBUG && args.debug && threadIdx.x == 0) args.debug[4096 + (i) * args.n_envs + blockIdx.x] += (float)(_t - stamp_last); \
     stamp_last = _t;                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                    \
   } while (0)
-#define STAMP2(i)                                                                         \
-  do {                                                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                    \
-    const unsigned long long _t = __builtin_amdgcn_s_memtime();                           \
-    __builtin_amdgcn_s_waitcnt(0xC07F);                                                   \
-    if (DEBUG && args.debug && blockIdx.x == 0 && threadIdx.x == 0) args.debug[3100 + 8 * sub + (i)] = (float)(_t - stamp_last); \
-    __builtin_amdgcn_sched_barrier(0);                                                    \
-  } while (0)
 #else
-#define STAMP(i) do {} while (0)
-#define STAMP2(i) do {} while (0)
+#define STAMP(i) asm volatile("; ---- phase mark " #i)
 #endif
 
 namespace {
 
-// ---------------------------------------------------------------- team (32-lane) primitives
-__device__ __forceinline__ float tshfl(float v, int src) { return __shfl(v, src, TL); }
-__device__ __forceinline__ int tshfl(int v, int src) { return __shfl(v, src, TL); }
-// all-reduce sum over the 32 lanes of a team on the VALU (no LDS round trips): four DPP adds inside
-// the 16-lane rows, then gfx950's v_permlane16_swap exchanges row 0<->1 and 2<->3.
+// ---------------------------------------------------------------- wave (64-lane) primitives
+__device__ __forceinline__ float wshfl(float v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ int wshfl(int v, int src) { return __shfl(v, src, 64); }
+// value held by lane `src` (src WAVE-uniform) through an SGPR: one v_readlane
+__device__ __forceinline__ float rl(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+__device__ __forceinline__ int rl(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ unsigned rl(unsigned v, int src) { return (unsigned)__builtin_amdgcn_readlane((int)v, src); }
+__device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// all-reduce over the 64 lanes on the VALU (no LDS round trips): four DPP steps inside the 16-lane rows,
+// then gfx950's v_permlane16_swap (rows 0<->1, 2<->3) and v_permlane32_swap (halves).
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float tsum(float v) {
-  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
-  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
-  v += dpp_mov<0x141>(v);  // row_half_mirror
-  v += dpp_mov<0x140>(v);  // row_mirror
-  const unsigned u = __float_as_uint(v);
-  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float wsum(float v) {   // all-reduce over the 64 lanes of the wave
-  v = tsum(v);
-  const unsigned u = __float_as_uint(v);
-  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float tminf(float v) {
-  v = fminf(v, dpp_mov<0xB1>(v));
-  v = fminf(v, dpp_mov<0x4E>(v));
-  v = fminf(v, dpp_mov<0x141>(v));
-  v = fminf(v, dpp_mov<0x140>(v));
-  const unsigned u = __float_as_uint(v);
-  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  return fminf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 template <int CTRL>
 __device__ __forceinline__ int dpp_mov_i(int v) {
   return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
 }
-__device__ __forceinline__ int tmini(int v) {   // non-negative values
+__device__ __forceinline__ float wsum(float v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  u = __float_as_uint(v);
+  r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float wminf(float v) {
+  v = fminf(v, dpp_mov<0xB1>(v));
+  v = fminf(v, dpp_mov<0x4E>(v));
+  v = fminf(v, dpp_mov<0x141>(v));
+  v = fminf(v, dpp_mov<0x140>(v));
+  unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = fminf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  u = __float_as_uint(v);
+  r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fminf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ int wmini(int v) {   // non-negative values
   v = min(v, dpp_mov_i<0xB1>(v));
   v = min(v, dpp_mov_i<0x4E>(v));
   v = min(v, dpp_mov_i<0x141>(v));
   v = min(v, dpp_mov_i<0x140>(v));
-  const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+  auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+  v = min((int)r[0], (int)r[1]);
+  r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
   return min((int)r[0], (int)r[1]);
 }
-// team arg-max with ties to the lowest index: returns the winning (score, index) on every lane
-__device__ __forceinline__ void targmax(float &score, int &index) {
-  const float best = -tminf(-score);
-  index = tmini(score == best ? index : 0x7fffffff);
-  score = best;
+// wave arg-max with ties to the lowest index: returns the winning (score, index) on every lane
+__device__ __forceinline__ void wargmax(float &score, int &index) {
+  const float best = -wminf(-score);
+  index = uni(wmini(score == best ? index : 0x7fffffff));
+  score = uni(best);
 }
-// value held by team lane `src` (src WAVE-uniform), through SGPRs: two v_readlane + one select
-__device__ __forceinline__ float tbcast(float v, int src) {
-  const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
-  const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src + 32));
-  return (threadIdx.x & 32) ? b : a;
-}
-__device__ __forceinline__ unsigned tballot(bool p) {
-  unsigned long long b = __ballot(p);
-  return (unsigned)(b >> (threadIdx.x & 32));
-}
-__device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 
 __device__ __forceinline__ void cross3(const float *a, const float *b, float *o) {
   float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
@@ -216,10 +211,9 @@ __device__ __forceinline__ void sym6_rank1_sub(Sym6 &m, const float *U, float s)
 
 // inverse of an SPD 6x6 (Cholesky), result as 21 unique entries of the symmetric inverse, row-major
 // upper triangle: inv[tri(r,c)], r<=c
-__device__ __forceinline__ int tri(int r, int c) { return r * 6 - r * (r - 1) / 2 + (c - r); }
-__device__ __forceinline__ void spd6_inverse(const Sym6 &m, float *inv21) {
-  float a[36], l[36];
-  sym6_full(m, a);
+__device__ __forceinline__ constexpr int tri(int r, int c) { return r * 6 - r * (r - 1) / 2 + (c - r); }
+__device__ __forceinline__ void spd6_inverse(const float *a, float *inv21) {   // a: full 6x6, row-major
+  float l[36];
 #pragma unroll
   for (int i = 0; i < 36; i++) l[i] = 0.f;
 #pragma unroll
@@ -266,29 +260,28 @@ __device__ __forceinline__ void inv21_mul(const float *inv21, const float *v, fl
   }
 }
 
-// ---------------------------------------------------------------- LDS layout (per wave = two envs)
-constexpr int NJMAX = TL - 7;            // 25 hinge joints at most (26 bodies + 6 base dofs = 32 lanes)
+// ---------------------------------------------------------------- LDS layout (per wave = one env)
+constexpr int NJMAX = 25;                // hinge joints at most (26 bodies)
 constexpr int NROW = NJMAX + 3 * MAXC;   // constraint rows of one env: 25 motor rows + 13 x (normal, 2 friction) = 64
-static_assert(NROW <= 64, "one constraint row per lane");
-// Row descriptors. Column side, read as a wave-wide broadcast: chain nodes ca[6] | zc[6] = u/D at those
-// nodes | z0[6] = I0^-1 r0. Own side, read once by the lane that owns the row: u[6] | r0[6] | 1/diag | scaled
-// right-hand side. Records: motor rows of env 0, motor rows of env 1 (staged once per substep, straight
-// after the factorisation), contact rows of the env being solved, one null record.
-constexpr int CROW0 = 2 * NJMAX;            // first contact record
-constexpr int NREC = CROW0 + 3 * MAXC + 1;  // 90 records, the last one null
-struct RowStage {
-  float4 col[NREC][5];        // 20 words per row (2 pad), 16-byte aligned broadcast reads      7200 B
-  float own[NREC][15];        // odd stride: conflict-free per-lane reads                       5400 B
-};
+static_assert(NROW == 64, "one constraint row per lane");
+constexpr int CLANE0 = NJMAX + 1;        // contact row k lives on lane CLANE0 + k (k < 38) and on lane 0 (k = 38)
+// Body record, parked after the tree phases and read by the row walks (float4 reads, 80-byte stride:
+// 16 lanes reading 16 different records hit 16 different bank quartets):
+//   q0 = joint axis (world) xyz | 1/D      q1 = origin r (rel. base origin) xyz | updated joint rate
+//   q2 = (U/D)[0..3]                       q3 = (U/D)[4..5] | parent + 256 * depth (int) | -
+//   q4 = offset from the parent's origin xyz | -
+constexpr int BREC = 5;                  // float4s per record
 struct WaveLds {
+  float4 body[32 * BREC];     // 2560 B; after the row walks: z0 stash [6][64] for the base twist change
   union {
-    float aba[2][TL][28];     // per team: tip-to-base staging, Ia (21) + pa (6) per body       7168 B
-    RowStage rows;            // afterwards: the row descriptors                               12600 B
+    float aba[32][28];        // tip-to-base staging, Ia (21) + pa (6) per body                3584 B
+    float jcol[NJMAX][64];    // [j-1][row lane]: B entries of motor column j (limit rows)     6400 B
   } u;
-  float jcol[NJMAX][64];      // [j-1][row lane]: B entries of motor column j                   6400 B
-  float i0inv[2][24];         // per team: inverse of the base's articulated inertia (21)        192 B
+  float cpt[MAXC][8];         // contact points: body, x, y, z (rel. base origin), distance     416 B
+  float st[6][TL];            // per body lane, parked across the phases: q, qd, motor torque, target, updated rate, 1/M^-1_jj  768 B
 };
-static_assert(sizeof(WaveLds) <= 20480, "8 workgroups per CU need <= 20 KB of LDS each");
+enum { ST_Q, ST_QD, ST_TAU, ST_TARGET, ST_NQD, ST_MDG };
+static_assert(sizeof(WaveLds) <= 10240, "16 workgroups per CU need <= 10 KB of LDS each");
 
 struct KernelArgs {
   const TrexDeviceModel *model;
@@ -309,118 +302,114 @@ struct KernelArgs {
 
 }  // namespace
 
-// DEBUG instantiations carry the diagnostics dump (tests, phase stamps); the product launches use
-// DEBUG = false so that none of the dump's address arithmetic exists in the shipped kernels.
+// DEBUG instantiations carry the diagnostics dump (scripts/gpu_debug.py, phase stamps); the product launches
+// use DEBUG = false so that none of the dump's address arithmetic exists in the shipped kernels.
 template <bool RESET, bool DEBUG>
-__global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
+__global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
   __shared__ WaveLds W;
-#if !TREX_STAMPS
-#define WPH(i) do {} while (0)
-#endif
-#if TREX_STAMPS
-  const unsigned long long wave_t0 = __builtin_amdgcn_s_memtime();
-  int dbg_bodies = 0, dbg_passes = 0, dbg_trips = 0;   // pass B: body iterations, passes, candidate trips
-  unsigned long long wph[5] = {0, 0, 0, 0, 0}, wph_t = wave_t0;   // per-wave phase cycles: tree, contacts, walk+build, sweeps, rest
-#define WPH(i) do { const unsigned long long _w = __builtin_amdgcn_s_memtime(); wph[i] += _w - wph_t; wph_t = _w; } while (0)
-  unsigned long long wave_cg = 0, wave_cg1 = 0, wave_cg2 = 0;   // cycles in contact generation: all, small-hull scan, large-hull scan
-#endif
-  const int lane = threadIdx.x & (TL - 1);
-  const int team = threadIdx.x >> 5;
+  const int tid = threadIdx.x;
   const TrexDeviceModel *__restrict__ M = args.model;
-  int env = blockIdx.x * 2 + team;   // wave slot
-  const bool env_ok = env < args.n_envs;
-  if (!env_ok) env = args.n_envs - 1;  // duplicate the last env's work, never store it
+  int env = blockIdx.x;
   if (args.perm) env = args.perm[env];
+  env = uni(env);
 
   const int nb = M->nb, maxdepth = M->maxdepth;
   const float dt = M->prm[TP_DT];
-  const float inv_dt = 1.0f / dt;
-  const bool is_body = lane < nb;
-  const bool is_joint = lane >= 1 && lane < nb;
-  const int bdof = lane - nb;  // 0..5 on base dof lanes
-  const bool is_base_dof = bdof >= 0 && bdof < 6;
-
-  // ---- model constants of this lane's body. Topology (integers) stays in registers for the whole
-  // launch; the geometric constants (24 floats) are re-read from the L2-resident model at the top of
-  // every substep instead of being carried - and spilled - across the solver loop.
-  const int parent = is_body ? M->parent[lane] : 0;
-  const int psrc = parent < 0 ? 0 : parent;
-  const int depth = is_body ? M->depth[lane] : -1;
-  // Everything else about the model is (re)read from the L2-resident struct in the phase that uses
-  // it, through an opaque pointer, so that no constant is live - and spilled - across the solver loop.
-  auto Mo = [&]() { const TrexDeviceModel *Mi = M; asm volatile("" : "+s"(Mi)); return Mi; };
-  int anc[MAXD];
-  float axis[3], jpos[3], jrot[9], comb[3], inb[6];
-  float mass = 0.f, mscale = 1.f, jdamp = 0.f;
-  auto load_body_constants = [&]() {
-    const TrexDeviceModel *Mi = Mo();
-    mscale = args.arr.mass_scale[env * TL + lane];
-    mass = Mi->mass[lane] * mscale;
-    jdamp = Mi->damp[lane];
-#pragma unroll
-    for (int c = 0; c < 3; c++) { axis[c] = Mi->axis[c][lane]; jpos[c] = Mi->jpos[c][lane]; comb[c] = Mi->com[c][lane]; }
-#pragma unroll
-    for (int c = 0; c < 9; c++) jrot[c] = Mi->jrot[c][lane];
-#pragma unroll
-    for (int c = 0; c < 6; c++) inb[c] = Mi->inertia[c][lane];
-  };
+  const float inv_dt = M->inv_dt;
   const int nj = nb - 1;
+  // Everything about the model is (re)read from the L2-resident struct in the phase that uses it, through an
+  // opaque pointer, and every lane-derived mask / index is re-derived from an opaque copy of the lane id, so
+  // that nothing loop-invariant is hoisted out of the substep loop and then spilled across the solver.
+  auto Mo = [&]() { const TrexDeviceModel *Mi = M; asm volatile("" : "+s"(Mi)); return Mi; };
+  auto lane_id = [&]() {   // (volatile: recomputed at every use site, never kept live or spilled)
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+  };
 
-  // ---- per-env state
-  float pos[3], quat[4], bv[3], bw[3], q, qd, mtau = 0.f;
-  const float mu = args.arr.friction[env];
+  // ---- per-env state: the base pose and twist are wave-uniform (SGPRs); q / qd / motor torque / target of
+  // body lane b are parked in LDS (W.st) and read where a phase needs them
+  float pos[3], quat[4], bv[3], bw[3];
+  const float mu = uni(args.arr.friction[env]);
   bool motors_on;
   bool do_reset = false;
+  bool bad;
   if (RESET) do_reset = args.reset_mask ? (args.reset_mask[env] != 0) : true;
-  if (RESET && do_reset) {
+  {
+    const bool is_body = tid < nb, is_joint = tid >= 1 && tid < nb;
+    float q = 0.f, qd = 0.f, mtau = 0.f, target = 0.f;
+    if (RESET && do_reset) {
 #pragma unroll
-    for (int c = 0; c < 3; c++) { pos[c] = M->base_pos0[c]; bv[c] = 0.f; bw[c] = 0.f; }
+      for (int c = 0; c < 3; c++) { pos[c] = uni(M->base_pos0[c]); bv[c] = 0.f; bw[c] = 0.f; }
 #pragma unroll
-    for (int c = 0; c < 4; c++) quat[c] = M->base_quat0[c];
-    q = M->q_start[lane]; qd = 0.f;
-    motors_on = false;  // remove_joint_control, trex_robot.py:309
-  } else {
-    const float *b = args.arr.base + env * 16;
+      for (int c = 0; c < 4; c++) quat[c] = uni(M->base_quat0[c]);
+      q = is_body ? M->q_start[tid & (TL - 1)] : 0.f;
+      motors_on = false;  // remove_joint_control, trex_robot.py:309
+    } else {
+      const float *b = args.arr.base + (size_t)env * 16;
 #pragma unroll
-    for (int c = 0; c < 3; c++) { pos[c] = b[c]; bv[c] = b[7 + c]; bw[c] = b[10 + c]; }
+      for (int c = 0; c < 3; c++) { pos[c] = uni(b[c]); bv[c] = uni(b[7 + c]); bw[c] = uni(b[10 + c]); }
 #pragma unroll
-    for (int c = 0; c < 4; c++) quat[c] = b[3 + c];
-    q = args.arr.q[env * TL + lane];
-    qd = args.arr.qd[env * TL + lane];
-    mtau = args.arr.tau[env * TL + lane];
-    motors_on = RESET ? (args.arr.motors_on[env] != 0) : true;
+      for (int c = 0; c < 4; c++) quat[c] = uni(b[3 + c]);
+      if (tid < TL) {
+        q = args.arr.q[(size_t)env * TL + tid];
+        qd = args.arr.qd[(size_t)env * TL + tid];
+        mtau = args.arr.tau[(size_t)env * TL + tid];
+      }
+      motors_on = RESET ? (args.arr.motors_on[env] != 0) : true;
+    }
+    // non-finite input state (checked here as well as after the step: fminf/fmaxf clamps launder NaNs)
+    bool badl = !(fabsf(q) < 3.0e38f) || !(fabsf(qd) < 3.0e38f);
+#pragma unroll
+    for (int k = 0; k < 3; k++) badl |= !(fabsf(pos[k]) < 3.0e38f) || !(fabsf(bv[k]) < 3.0e38f) || !(fabsf(bw[k]) < 3.0e38f);
+#pragma unroll
+    for (int k = 0; k < 4; k++) badl |= !(fabsf(quat[k]) < 3.0e38f);
+    bad = __ballot(badl) != 0ull;
+    if (!RESET && is_joint) {
+      const float a = args.actions[(size_t)env * nj + M->obs_slot[tid]];
+      target = fminf(fmaxf(a, M->lower[tid]), M->upper[tid]);  // np.clip, trex_env.py:147
+    }
+    if (tid < TL) {
+      W.st[ST_Q][tid] = q; W.st[ST_QD][tid] = qd; W.st[ST_TAU][tid] = mtau; W.st[ST_TARGET][tid] = target;
+      W.st[ST_NQD][tid] = 0.f;
+    }
   }
-  // non-finite input state (checked here as well as after the step: fminf/fmaxf clamps launder NaNs)
-  bool bad = !(fabsf(q) < 3.0e38f) || !(fabsf(qd) < 3.0e38f);
-#pragma unroll
-  for (int k = 0; k < 3; k++) bad |= !(fabsf(pos[k]) < 3.0e38f) || !(fabsf(bv[k]) < 3.0e38f) || !(fabsf(bw[k]) < 3.0e38f);
-#pragma unroll
-  for (int k = 0; k < 4; k++) bad |= !(fabsf(quat[k]) < 3.0e38f);
-  float target = 0.f;
-  if (!RESET && is_joint) {
-    const float a = args.actions[env * nj + M->obs_slot[lane]];
-    target = fminf(fmaxf(a, M->lower[lane]), M->upper[lane]);  // np.clip, trex_env.py:147
-  }
-  const int n_sub = RESET ? (do_reset ? 1 : 0) : (int)M->prm[TP_SUBSTEPS];
-  // a team that does not reset still walks through the loop when its wave partner resets
-  const int n_sub_wave = RESET ? (wave_any(do_reset) ? 1 : 0) : n_sub;
+  __syncthreads();
+  const int n_sub = RESET ? (do_reset ? 1 : 0) : M->n_substeps;
+  // Wave priority: the launch lasts as long as its slowest wave, and with one env per wave that is an env with
+  // many contact rows. During its sweeps such a wave wins the issue arbitration against the lighter waves of
+  // its SIMD, which fill the slots its dependency chain leaves empty. (Mode 2, priority for the whole substep,
+  // starved the light waves instead: 3.84 M against 4.12 M env-steps/s.)
+  auto set_priority = [](int contacts) {
+    if (contacts >= 10) __builtin_amdgcn_s_setprio(3);
+    else if (contacts >= 6) __builtin_amdgcn_s_setprio(2);
+    else if (contacts >= 3) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+  };
+#if TREX_PRIO_MODE == 2
+  if (!RESET) set_priority(uni(args.arr.contact_count[env]));
+#endif
 
-  const float grav = M->prm[TP_GRAVITY], kdamp = M->prm[TP_LINK_DAMPING], vmax = M->prm[TP_MAX_COORD_VEL];
   const float floor_z = M->prm[TP_FLOOR_Z], margin = M->prm[TP_CONTACT_MARGIN];
-  const float erp = M->prm[TP_ERP], cerp = M->prm[TP_CONTACT_ERP];
-  const float kp = M->prm[TP_MOTOR_KP], kd = M->prm[TP_MOTOR_KD], max_imp = M->prm[TP_MOTOR_MAX_FORCE] * dt;
-  const int iters = (int)M->prm[TP_ITERATIONS];
-  int maxc = (int)M->prm[TP_MAX_CONTACTS];
+  const int iters = M->n_iterations;
+  int maxc = M->max_contacts;
   if (maxc > MAXC) maxc = MAXC;
 
-  // kinematic quantities of this lane's body
-  float R[9], r[3], dpar[3] = {0.f, 0.f, 0.f}, S[6];   // dpar = r - r(parent), world axes
   int stat_nc = 0;
   float stat_imp = 0.f;
 
-  // FK: world rotation R and origin r (relative to the base origin) of every body; joint motion
-  // subspace about the body's own origin S = [a; 0].  (base-to-tip, parent data via shuffles)
-  auto forward_kinematics = [&]() {
+  // FK: world rotation R and origin r (relative to the base origin) of every body, the offset dpar from the
+  // parent's origin and the joint axis Sa in world axes (motion subspace about the body's own origin
+  // S = [Sa; 0]).  Base-to-tip, parent data via shuffles.
+  auto forward_kinematics = [&](int lt, int psrc, int depth, float *R, float *r, float *dpar, float *Sa) {
+    const TrexDeviceModel *Mi = Mo();
+    const int bl = lt & (TL - 1);
+    float axis[3], jpos[3], jrot[9];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { axis[c] = Mi->axis[c][bl]; jpos[c] = Mi->jpos[c][bl]; }
+#pragma unroll
+    for (int c = 0; c < 9; c++) jrot[c] = Mi->jrot[c][bl];
+    const float q = W.st[ST_Q][bl];
     float Rl[9];
     {
       // jrot * Rot(axis, q)
@@ -432,12 +421,13 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
     }
     quat_to_mat(quat, R);
     r[0] = r[1] = r[2] = 0.f;
+    dpar[0] = dpar[1] = dpar[2] = 0.f;
     for (int d = 1; d <= maxdepth; d++) {
       float pR[9], pr[3];
 #pragma unroll
-      for (int c = 0; c < 9; c++) pR[c] = tshfl(R[c], psrc);
+      for (int c = 0; c < 9; c++) pR[c] = wshfl(R[c], psrc);
 #pragma unroll
-      for (int c = 0; c < 3; c++) pr[c] = tshfl(r[c], psrc);
+      for (int c = 0; c < 3; c++) pr[c] = wshfl(r[c], psrc);
       if (depth == d) {
         float o[3];
         matmul3(pR, Rl, R);
@@ -446,388 +436,69 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
         for (int c = 0; c < 3; c++) { dpar[c] = o[c]; r[c] = pr[c] + o[c]; }
       }
     }
-    float a[3];
-    matvec3(R, axis, a);
-    S[0] = a[0]; S[1] = a[1]; S[2] = a[2];
-    S[3] = S[4] = S[5] = 0.f;
-    if (!is_joint) {
-#pragma unroll
-      for (int c = 0; c < 6; c++) S[c] = 0.f;
-    }
+    matvec3(R, axis, Sa);
+    if (!(lt >= 1 && lt < nb)) { Sa[0] = Sa[1] = Sa[2] = 0.f; }
   };
 
-  // spatial velocity of every body ABOUT ITS OWN ORIGIN for base twist (w, v) and joint rates
-  auto body_velocities = [&](const float *w, const float *v, float rate, float *vel) {
-#pragma unroll
-    for (int c = 0; c < 3; c++) { vel[c] = w[c]; vel[3 + c] = v[c]; }
-    for (int d = 1; d <= maxdepth; d++) {
-      float pv[6];
-#pragma unroll
-      for (int c = 0; c < 6; c++) pv[c] = tshfl(vel[c], psrc);
-      if (depth == d) {
-        float wxd[3];
-        cross3(pv, dpar, wxd);   // velocity of the parent-body point at this body's origin
-#pragma unroll
-        for (int c = 0; c < 3; c++) { vel[c] = pv[c] + S[c] * rate; vel[3 + c] = pv[3 + c] + wxd[c]; }
+#if TREX_STAMPS
+  unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll 1
+  for (int sub = 0; sub < n_sub; sub++) {
+    // lane id and what derives from it are RE-derived at the start of every phase (RELANE): a value that
+    // lived from the top of the substep would be spilled across the phases in between
+    int lt, bl;                        // bl: index into the [32]-wide model / state rows (lanes >= 32 alias, never used)
+    bool is_body, is_joint;
+#define RELANE() do { lt = lane_id(); bl = lt & (TL - 1); is_body = lt < nb; is_joint = lt >= 1 && lt < nb; } while (0)
+    RELANE();
+    int psrc, depth;
+    {
+      const TrexDeviceModel *Mi = Mo();
+      const int parent = is_body ? Mi->parent[bl] : 0;
+      psrc = parent < 0 ? 0 : parent;
+      depth = is_body ? Mi->depth[bl] : -1;
+    }
+    float R[9], r[3];
+    float Sa[3], dpar[3];   // joint axis (world) and offset from the parent's origin: re-read from the record per phase
+    {
+      float dpar0[3], Sa0[3];
+      forward_kinematics(lt, psrc, depth, R, r, dpar0, Sa0);
+      if (lt < TL) {   // what later phases need of this body's pose and place in the tree goes to its record now
+        float4 *rec = &W.body[BREC * lt];
+        rec[0] = make_float4(Sa0[0], Sa0[1], Sa0[2], 0.f);
+        rec[1] = make_float4(r[0], r[1], r[2], 0.f);
+        rec[3] = make_float4(0.f, 0.f, __int_as_float(psrc + 256 * (depth < 0 ? 255 : depth)), 0.f);
+        rec[4] = make_float4(dpar0[0], dpar0[1], dpar0[2], 0.f);
       }
     }
-  };
-
-  for (int sub = 0; sub < n_sub_wave; sub++) {
-    const bool live = sub < n_sub;  // this team really advances
-#if TREX_STAMPS
-    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
-#endif
-    // `ls` = lane, opaque to the optimiser once per substep: lane-derived masks and unit vectors are
-    // then recomputed where used (1 VALU) instead of being hoisted out of the loop and spilled.
-    int ls = lane;
-    asm volatile("" : "+v"(ls));
-    const int bdof_s = ls - nb;
-    const bool is_base_dof_s = bdof_s >= 0 && bdof_s < 6;
-    load_body_constants();
-    forward_kinematics();
-    float vel[6];
-    body_velocities(bw, bv, qd, vel);
-
+    // (axis, parent offset, parent and depth are re-read from the record by the phases that sweep the tree)
+#define REAXIS() do { const float4 q0_ = W.body[BREC * bl], q4_ = W.body[BREC * bl + 4];                          \
+                      Sa[0] = is_joint ? q0_.x : 0.f; Sa[1] = is_joint ? q0_.y : 0.f; Sa[2] = is_joint ? q0_.z : 0.f; \
+                      dpar[0] = q4_.x; dpar[1] = q4_.y; dpar[2] = q4_.z; } while (0)
+#define RETREE() do { const int lk_ = __float_as_int(reinterpret_cast<const float *>(&W.body[BREC * bl + 3])[2]); \
+                      psrc = lk_ & 255; depth = is_body ? (lk_ >> 8) : -1; } while (0)
     STAMP(0);
-    // ---- rigid-body spatial inertia about the body origin, bias force, velocity-product acceleration
-    float comw[3], Icw[6];   // comw = COM offset from the body origin, world axes
-    {
-      matvec3(R, comb, comw);
-      // Ic_world = R Ib R^T (symmetric)
-      float t[9];
-      const float Ib[9] = {inb[0], inb[1], inb[2], inb[1], inb[3], inb[4], inb[2], inb[4], inb[5]};
-      matmul3(R, Ib, t);
-      const int ia[6] = {0, 0, 0, 1, 1, 2}, ib[6] = {0, 1, 2, 1, 2, 2};
-#pragma unroll
-      for (int k = 0; k < 6; k++)
-        Icw[k] = mscale * (t[3 * ia[k]] * R[3 * ib[k]] + t[3 * ia[k] + 1] * R[3 * ib[k] + 1] + t[3 * ia[k] + 2] * R[3 * ib[k] + 2]);
-    }
-    Sym6 IA;
-    {
-      const float cc = dot3(comw, comw);
-      IA.A[0] = Icw[0] + mass * (cc - comw[0] * comw[0]);
-      IA.A[1] = Icw[1] - mass * comw[0] * comw[1];
-      IA.A[2] = Icw[2] - mass * comw[0] * comw[2];
-      IA.A[3] = Icw[3] + mass * (cc - comw[1] * comw[1]);
-      IA.A[4] = Icw[4] - mass * comw[1] * comw[2];
-      IA.A[5] = Icw[5] + mass * (cc - comw[2] * comw[2]);
-      // B = m * [c]x
-      IA.B[0] = 0.f;              IA.B[1] = -mass * comw[2];  IA.B[2] = mass * comw[1];
-      IA.B[3] = mass * comw[2];   IA.B[4] = 0.f;              IA.B[5] = -mass * comw[0];
-      IA.B[6] = -mass * comw[1];  IA.B[7] = mass * comw[0];   IA.B[8] = 0.f;
-      IA.C[0] = mass; IA.C[1] = 0.f; IA.C[2] = 0.f; IA.C[3] = mass; IA.C[4] = 0.f; IA.C[5] = mass;
-    }
-    if (!is_body) {
-#pragma unroll
-      for (int k = 0; k < 6; k++) { IA.A[k] = (k == 0 || k == 3 || k == 5) ? 1.f : 0.f; IA.C[k] = IA.A[k]; }
-#pragma unroll
-      for (int k = 0; k < 9; k++) IA.B[k] = 0.f;
-    }
-    float pA[6], cv[6];
-    {
-      float h[6];
-      sym6_mul(IA, vel, h);
-      // v x* h
-      float a[3], b[3], c[3];
-      cross3(vel, h, a); cross3(vel + 3, h + 3, b); cross3(vel, h + 3, c);
-#pragma unroll
-      for (int k = 0; k < 3; k++) { pA[k] = a[k] + b[k]; pA[3 + k] = c[k]; }
-      float f[3] = {0.f, 0.f, -mass * grav}, n[3] = {0.f, 0.f, 0.f};
-      if (kdamp > 0.f) {
-        float vc[3], wxc[3], Iw[3];
-        cross3(vel, comw, wxc);
-#pragma unroll
-        for (int k = 0; k < 3; k++) vc[k] = vel[3 + k] + wxc[k];
-        const float sv = sqrtf(dot3(vc, vc)), sw = sqrtf(dot3(vel, vel));
-        sym3_mul(Icw, vel, Iw);
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-          f[k] -= mass * vc[k] * (kdamp + kdamp * sv);
-          n[k] -= Iw[k] * (kdamp + kdamp * sw);
-        }
-      }
-      float cxf[3];
-      cross3(comw, f, cxf);
-#pragma unroll
-      for (int k = 0; k < 3; k++) { pA[k] -= n[k] + cxf[k]; pA[3 + k] -= f[k]; }
-      // c = vel x (S qd)
-      float sq[6];
-#pragma unroll
-      for (int k = 0; k < 6; k++) sq[k] = S[k] * qd;
-      float x0[3], x1[3], x2[3];
-      cross3(vel, sq, x0); cross3(vel, sq + 3, x1); cross3(vel + 3, sq, x2);
-#pragma unroll
-      for (int k = 0; k < 3; k++) { cv[k] = x0[k]; cv[3 + k] = x1[k] + x2[k]; }
-      if (!is_body) {
-#pragma unroll
-        for (int k = 0; k < 6; k++) { pA[k] = 0.f; cv[k] = 0.f; }
-      }
-    }
 
-    STAMP(1);
-    // ---- ABA pass 2 (tip to base): articulated inertias and bias forces through LDS
-    float U[6], Ud[6], invD = 0.f, u = 0.f;
-#pragma unroll
-    for (int k = 0; k < 6; k++) { U[k] = 0.f; Ud[k] = 0.f; }
-    const float tau_j = -jdamp * qd;  // explicit joint damping torque
-    int child[MAXCH];
-    {
-      const TrexDeviceModel *Mi = Mo();
-#pragma unroll
-      for (int k = 0; k < MAXCH; k++) child[k] = is_body ? Mi->child[k][lane] : -1;
-    }
-    for (int d = maxdepth; d >= 1; d--) {
-      if (depth == d) {
-        sym6_mul(IA, S, U);
-        invD = 1.0f / dot6(S, U);
-#pragma unroll
-        for (int k = 0; k < 6; k++) Ud[k] = U[k] * invD;
-        u = tau_j - dot6(S, pA);
-        float Ic[6];
-        sym6_mul(IA, cv, Ic);
-        const float uc = dot6(U, cv);
-        Sym6 Ia = IA;
-        sym6_rank1_sub(Ia, U, invD);
-        float pa[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) pa[k] = pA[k] + Ic[k] + U[k] * (u - uc) * invD;
-        // shift both to the parent's origin (this origin = parent origin + dpar):
-        //   B' = B + [d]x C,  A' = A - B [d]x + [d]x B'^T,  C' = C,  n' = n + d x f
-        {
-          const int sidx[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
-          float Bn[9], BD[9], DBt[9];
-#pragma unroll
-          for (int j = 0; j < 3; j++) {   // column j of [d]x C = d x (column j of C)
-            const float cj[3] = {Ia.C[sidx[0][j]], Ia.C[sidx[1][j]], Ia.C[sidx[2][j]]};
-            float t[3];
-            cross3(dpar, cj, t);
-#pragma unroll
-            for (int i = 0; i < 3; i++) Bn[3 * i + j] = Ia.B[3 * i + j] + t[i];
-          }
-#pragma unroll
-          for (int i = 0; i < 3; i++) {   // row i of B [d]x = -(d x row i of B)
-            float t[3];
-            cross3(dpar, Ia.B + 3 * i, t);
-#pragma unroll
-            for (int j = 0; j < 3; j++) BD[3 * i + j] = -t[j];
-          }
-#pragma unroll
-          for (int j = 0; j < 3; j++) {   // column j of [d]x B'^T = d x (row j of B')
-            float t[3];
-            cross3(dpar, Bn + 3 * j, t);
-#pragma unroll
-            for (int i = 0; i < 3; i++) DBt[3 * i + j] = t[i];
-          }
-          const int ia6[6] = {0, 0, 0, 1, 1, 2}, ib6[6] = {0, 1, 2, 1, 2, 2};
-#pragma unroll
-          for (int k = 0; k < 6; k++) {   // symmetric part (exactly symmetric in exact arithmetic)
-            const int ij = 3 * ia6[k] + ib6[k], ji = 3 * ib6[k] + ia6[k];
-            Ia.A[k] += 0.5f * ((DBt[ij] - BD[ij]) + (DBt[ji] - BD[ji]));
-          }
-#pragma unroll
-          for (int k = 0; k < 9; k++) Ia.B[k] = Bn[k];
-          float dxf[3];
-          cross3(dpar, pa + 3, dxf);
-#pragma unroll
-          for (int k = 0; k < 3; k++) pa[k] += dxf[k];
-        }
-        float *o = W.u.aba[team][lane];
-#pragma unroll
-        for (int k = 0; k < 6; k++) { o[k] = Ia.A[k]; o[15 + k] = Ia.C[k]; o[21 + k] = pa[k]; }
-#pragma unroll
-        for (int k = 0; k < 9; k++) o[6 + k] = Ia.B[k];
-      }
-      __syncthreads();
-      if (depth == d - 1) {
-#pragma unroll
-        for (int kc = 0; kc < MAXCH; kc++) {
-          const int ch = child[kc];
-          if (ch >= 0) {
-            const float *o = W.u.aba[team][ch];
-#pragma unroll
-            for (int k = 0; k < 6; k++) { IA.A[k] += o[k]; IA.C[k] += o[15 + k]; pA[k] += o[21 + k]; }
-#pragma unroll
-            for (int k = 0; k < 9; k++) IA.B[k] += o[6 + k];
-          }
-        }
-      }
-      __syncthreads();
-    }
-
-    STAMP(2);
-    // ---- floating base: a0 = -(IA_0)^-1 pA_0 ; broadcast the inverse to the whole team
-    float I0inv[21], a0[6];
-    {
-      float inv_l[21];
-      spd6_inverse(IA, inv_l);
-#pragma unroll
-      for (int k = 0; k < 21; k++) I0inv[k] = tshfl(inv_l[k], 0);
-      float p0[6];
-#pragma unroll
-      for (int k = 0; k < 6; k++) p0[k] = -tshfl(pA[k], 0);
-      inv21_mul(I0inv, p0, a0);
-      if (lane < 21) {   // parked for the contact rows: not carried in registers across contact generation
-        float v = I0inv[0];
-#pragma unroll
-        for (int k = 1; k < 21; k++) v = (lane == k) ? I0inv[k] : v;
-        W.i0inv[team][lane] = v;
-      }
-    }
-    STAMP(3);
-    // ---- ABA pass 3 (base to tip): accelerations
-    float qdd = 0.f;
-    {
-      float acc[6];
-#pragma unroll
-      for (int k = 0; k < 6; k++) acc[k] = a0[k];
-      for (int d = 1; d <= maxdepth; d++) {
-        float pa[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) pa[k] = tshfl(acc[k], psrc);
-        if (depth == d) {
-          float axd[3];
-          cross3(pa, dpar, axd);   // parent acceleration seen at this body's origin
-#pragma unroll
-          for (int k = 0; k < 3; k++) pa[3 + k] += axd[k];
-#pragma unroll
-          for (int k = 0; k < 6; k++) pa[k] += cv[k];
-          qdd = (u - dot6(U, pa)) * invD;
-#pragma unroll
-          for (int k = 0; k < 6; k++) acc[k] = pa[k] + S[k] * qdd;
-        }
-      }
-    }
-    // ---- unconstrained velocity update; vg = this dof lane's generalised velocity
-    float nw[3], nv[3];
-    {
-      float wxv[3];
-      cross3(bw, bv, wxv);
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        nw[k] = fminf(fmaxf(bw[k] + a0[k] * dt, -vmax), vmax);
-        nv[k] = fminf(fmaxf(bv[k] + (a0[3 + k] + wxv[k]) * dt, -vmax), vmax);
-      }
-    }
-    float nqd = fminf(fmaxf(qd + qdd * dt, -vmax), vmax);
-    float vg = is_joint ? nqd : 0.f;
-    // dof-lane motion subspace about the dof's own origin: joint lanes S about r, base dof lanes unit
-    // vectors about O
-    float Sd[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-      Sd[k] = is_joint ? S[k] : ((is_base_dof_s && bdof_s == k) ? 1.f : 0.f);
-      if (is_base_dof_s && bdof_s == k) vg = (k < 3) ? nw[k] : nv[k - 3];
-    }
-
-    STAMP(4);
-    // ---- distributed factorisation M^-1 = A^T B A: this lane's column of A
-    //   Aanc[d-1] = entry at its ancestor of depth d (1 at its own depth), A0 = base block entry,
-    //   Z[d-1]    = Aanc[d-1] / D(ancestor), g = I0inv * A0
-    float Aanc[MAXD], Z[MAXD], A0[6], g[6];
-    {
-      const TrexDeviceModel *Mi = Mo();
-#pragma unroll
-      for (int d = 0; d < MAXD; d++) anc[d] = is_body ? Mi->anc[d][lane] : -1;
-    }
-    {
-      float p[6], po[3];   // force p about the point po (starts at this joint's origin, walks up)
-#pragma unroll
-      for (int k = 0; k < 6; k++) p[k] = is_joint ? Ud[k] : 0.f;
-#pragma unroll
-      for (int k = 0; k < 3; k++) po[k] = r[k];
-#pragma unroll
-      for (int d = MAXD; d >= 1; d--) {
-        Aanc[d - 1] = 0.f; Z[d - 1] = 0.f;
-        if (d <= maxdepth) {
-          const int a = anc[d - 1] < 0 ? 0 : anc[d - 1];
-          float aa[3], Uda[6], ra[3];
-#pragma unroll
-          for (int k = 0; k < 3; k++) { aa[k] = tshfl(S[k], a); ra[k] = tshfl(r[k], a); }
-#pragma unroll
-          for (int k = 0; k < 6; k++) Uda[k] = tshfl(Ud[k], a);
-          const float invDa = tshfl(invD, a);
-          if (is_joint && depth == d) { Aanc[d - 1] = 1.f; Z[d - 1] = invD; }
-          else if (is_joint && depth > d) {
-            float dd[3], dxf[3];
-#pragma unroll
-            for (int k = 0; k < 3; k++) { dd[k] = po[k] - ra[k]; po[k] = ra[k]; }
-            cross3(dd, p + 3, dxf);
-#pragma unroll
-            for (int k = 0; k < 3; k++) p[k] += dxf[k];
-            const float ua = -dot3(aa, p);
-            Aanc[d - 1] = ua; Z[d - 1] = ua * invDa;
-#pragma unroll
-            for (int k = 0; k < 6; k++) p[k] += Uda[k] * ua;
-          }
-        }
-      }
-      {
-        float dxf[3];
-        cross3(po, p + 3, dxf);   // on to the base origin O
-#pragma unroll
-        for (int k = 0; k < 3; k++) p[k] += dxf[k];
-      }
-#pragma unroll
-      for (int k = 0; k < 6; k++) A0[k] = is_joint ? -p[k] : ((is_base_dof_s && bdof_s == k) ? 1.f : 0.f);
-      inv21_mul(I0inv, A0, g);
-    }
-    // Diagonal of M^-1 on the joint lanes (motor / limit rows are unit rows): a^T B a of this lane's own
-    // column of A.
-    STAMP(5);
-    float mdiag = 1.f;
-    if (is_joint) {
-      mdiag = dot6(A0, g);
-#pragma unroll
-      for (int d = 0; d < MAXD; d++) mdiag += Aanc[d] * Z[d];
-    }
-
-    STAMP(6);
-    // ---- joint rows: limits (unilateral, ERP) and position motors
-    const float inv_mdiag = 1.0f / mdiag;
-    float lim_dir = 0.f, lim_rhs = 0.f, lim_lam = 0.f;
-    if (is_joint) {
-      const TrexDeviceModel *Mi = Mo();
-      const float q_lo = Mi->lower[lane], q_hi = Mi->upper[lane];
-      float pen = 0.f;
-      if (q - q_lo <= 0.f) { pen = q - q_lo; lim_dir = 1.f; }
-      else if (q_hi - q <= 0.f) { pen = q_hi - q; lim_dir = -1.f; }
-      lim_rhs = (-pen * erp * inv_dt - lim_dir * vg) * inv_mdiag;
-    }
-    const unsigned lim_mask = tballot(lim_dir != 0.f);
-    float mot_rhs = 0.f, mot_lam = 0.f;
-    const float mot_hi = (is_joint && motors_on) ? max_imp : 0.f;
-    if (is_joint) {
-      // btMultiBodyJointMotor velocity target: kp*(target-q)/dt + qd + kd*(0-qd), minus current qd
-      const float tv = kp * (target - q) * inv_dt + vg + kd * (0.f - vg);
-      mot_rhs = (tv - vg) * inv_mdiag;
-    }
-
-    STAMP(7);
-    WPH(0);
-#if TREX_STAMPS
-    const unsigned long long cg_t0 = __builtin_amdgcn_s_memtime();
-#endif
-    // ---- contact generation: hull vertices against z <= floor_z
-    // Pass A walks the near bodies once: it finds whether a body has any vertex inside the margin and,
-    // in the same sweep, its DEEPEST such vertex (= the first point the selection rule keeps), parked in
-    // lane b's registers. Pass B revisits a body's vertices only when more than one point per body is
-    // kept (K >= 2, i.e. fewer than 8 bodies touch).
+    // ================================================================ contact generation
+    // hull vertices against z <= floor_z. Pass A walks the near bodies once: it finds whether a body has any
+    // vertex inside the margin and, in the same sweep, its DEEPEST such vertex (= the first point the
+    // selection rule keeps), parked in lane b's registers, and - as bit masks - WHICH vertices are inside.
+    // Pass B revisits a body's in-margin vertices only when more than one point per body is kept (K >= 2).
+    // The points go to LDS (W.cpt) in contact order; only their number nc stays in a register.
     int nc = 0;
-    int cbody = 0;
-    float cx[3] = {0.f, 0.f, 0.f}, cdist = 0.f;
     {
       const TrexDeviceModel *Mi = Mo();
-      const int hull_v0 = Mi->hull_start[lane < nb ? lane : nb], hull_v1 = Mi->hull_start[lane < nb ? lane + 1 : nb];
+      const int hull_v0 = Mi->hull_start[is_body ? lt : nb], hull_v1 = Mi->hull_start[is_body ? lt + 1 : nb];
       float sc[3];
-      float sph[3], boxh[3];   // read here, not at the top of the substep: not carried across the ABA passes
+      float sph[3], boxh[3];
 #pragma unroll
-      for (int c = 0; c < 3; c++) { sph[c] = Mi->sphere[c][lane]; boxh[c] = Mi->box_half[c][lane]; }
+      for (int c = 0; c < 3; c++) { sph[c] = Mi->sphere[c][bl]; boxh[c] = Mi->box_half[c][bl]; }
       matvec3(R, sph, sc);
       // broad phase: lowest point of the hull's oriented bounding box (conservative, much tighter than
       // a sphere for the long bones): z_centre - sum_k |R_zk| half_k
       const float reach = fabsf(R[6]) * boxh[0] + fabsf(R[7]) * boxh[1] + fabsf(R[8]) * boxh[2];
-      const bool near = is_body && hull_v1 > hull_v0 && (pos[2] + r[2] + sc[2] - reach - floor_z < margin);
+      const float zb = pos[2] + r[2] - floor_z;    // body origin above the floor
+      const bool near = is_body && hull_v1 > hull_v0 && (zb + sc[2] - reach < margin);
       unsigned active_mask = 0u;
       float a_x[3] = {0.f, 0.f, 0.f}, a_d = 0.f;   // lane b: deepest candidate of body b
       int a_v = -1;
@@ -837,15 +508,15 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       const int nverts = hull_v1 - hull_v0;
       const bool small = near && nverts <= SMALL_HULL;
       // In-margin vertex sets, kept for the point selection (pass B never sweeps a hull again): a small body's
-      // lane keeps bit i of cm[i / 32] for its vertex i; for the (at most two) large bodies every team lane
-      // keeps bit i for its strided vertex v0 + lane + 32 i.
+      // lane keeps bit i of cm[i / 32] for its vertex i; for the (at most two) large bodies every lane keeps
+      // bit i for its strided vertex v0 + lane + 64 i.
       unsigned cm0 = 0u, cm1 = 0u, cm2 = 0u;
       unsigned imL0 = 0u, imL1 = 0u;
       int bL0 = -1, bL1 = -1;
-      if (wave_any(small)) {
+      if (__ballot(small) != 0ull) {
         float bs = -3.0e38f;
-        constexpr int UN = 16;   // 16 independent 16-B loads in flight per lane (256 contiguous bytes)
-        for (int i0 = 0; wave_any(small && i0 < nverts); i0 += UN) {
+        constexpr int UN = 8;   // independent 16-B loads in flight per lane
+        for (int i0 = 0; __ballot(small && i0 < nverts) != 0ull; i0 += UN) {
           unsigned bm = 0u;
           float4 h[UN];
 #pragma unroll
@@ -859,12 +530,12 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
             // only the height decides; the winner's position is formed once, after the scan.
             // h.w = support radius (0 for a hull vertex): the contact point is the sphere's lowest point
             const float wz = R[6] * h[u].x + R[7] * h[u].y + R[8] * h[u].z;
-            const float dd = pos[2] + r[2] + wz - h[u].w - floor_z;
+            const float dd = zb + wz - h[u].w;
             const bool in = small && i < nverts && dd < margin;
             bm |= in ? (1u << u) : 0u;
             if (in && -dd > bs) { bs = -dd; a_v = hull_v0 + i; a_d = dd; }
           }
-          const unsigned add = bm << (i0 & 16);
+          const unsigned add = bm << (i0 & 24);
           if ((i0 >> 5) == 0) cm0 |= add;
           else if ((i0 >> 5) == 1) cm1 |= add;
           else cm2 |= add;
@@ -876,130 +547,113 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
           matvec3(R, hv, w);
           a_x[0] = r[0] + w[0]; a_x[1] = r[1] + w[1]; a_x[2] = r[2] + w[2] - hw.w;
         }
-        active_mask |= tballot(small && a_v >= 0);
+        active_mask |= (unsigned)__ballot(small && a_v >= 0);
       }
-#if TREX_STAMPS
-      const unsigned long long cg_t1 = __builtin_amdgcn_s_memtime();
-      wave_cg1 += cg_t1 - cg_t0;
-#endif
-      STAMP2(0);
-      // (ii) large hulls (cranium, pelvis+ribcage): the team strides over the vertices together
-      unsigned near_mask = tballot(near && !small);
-      while (wave_any(near_mask != 0u)) {
-        const bool valid = near_mask != 0u;
-        const int b = valid ? (__ffs(near_mask) - 1) : 0;
+      // (ii) large hulls (cranium, pelvis+ribcage): the wave strides over the vertices together
+      unsigned near_mask = (unsigned)__ballot(near && !small);
+      while (near_mask != 0u) {
+        const int b = __ffs(near_mask) - 1;
         near_mask &= near_mask - 1u;
-        float Rb[9], rb[3];
+        float Rb[3], rbz;     // only the z row and z origin decide
 #pragma unroll
-        for (int c = 0; c < 9; c++) Rb[c] = tshfl(R[c], b);
-#pragma unroll
-        for (int c = 0; c < 3; c++) rb[c] = tshfl(r[c], b);
-        const int v0 = tshfl(hull_v0, b), v1 = tshfl(hull_v1, b);
-        float bs = -3.0e38f, bx[3] = {0.f, 0.f, 0.f};
+        for (int c = 0; c < 3; c++) Rb[c] = rl(R[6 + c], b);
+        rbz = rl(zb, b);
+        const int v0 = rl(hull_v0, b), v1 = rl(hull_v1, b);
+        float bs = -3.0e38f;
         int bi = 0x7fffffff;
         unsigned im = 0u;
-        constexpr int UL = 4;   // 4 coalesced 512-B loads in flight per team
-        for (int it0 = 0; wave_any(valid && v0 + TL * it0 < v1); it0 += UL) {
+        constexpr int UL = 4;   // 4 coalesced 1-KB loads in flight per wave
+        for (int it0 = 0; v0 + 64 * it0 < v1; it0 += UL) {
           float4 h[UL];
 #pragma unroll
           for (int u = 0; u < UL; u++) {
-            const int v = v0 + lane + TL * (it0 + u);
-            h[u] = args.arr.hull[(valid && v < v1) ? v : v0];
+            const int v = v0 + lt + 64 * (it0 + u);
+            h[u] = args.arr.hull[v < v1 ? v : v0];
           }
 #pragma unroll
           for (int u = 0; u < UL; u++) {
-            const int v = v0 + lane + TL * (it0 + u);
-            const float wz = Rb[6] * h[u].x + Rb[7] * h[u].y + Rb[8] * h[u].z;   // the height decides
-            const float dd = pos[2] + rb[2] + wz - h[u].w - floor_z;
-            if (valid && v < v1 && dd < margin) {
+            const int v = v0 + lt + 64 * (it0 + u);
+            const float wz = Rb[0] * h[u].x + Rb[1] * h[u].y + Rb[2] * h[u].z;   // the height decides
+            const float dd = rbz + wz - h[u].w;
+            if (v < v1 && dd < margin) {
               im |= (it0 + u < 32) ? (1u << (it0 + u)) : 0u;
               if (-dd > bs) { bs = -dd; bi = v; }
             }
           }
         }
-        if (bi != 0x7fffffff) {   // position of this lane's deepest vertex, once
-          const float4 hw = args.arr.hull[bi];
-          const float hv[3] = {hw.x, hw.y, hw.z};
-          float w[3];
-          matvec3(Rb, hv, w);
-          bx[0] = rb[0] + w[0]; bx[1] = rb[1] + w[1]; bx[2] = rb[2] + w[2] - hw.w;
-        }
-        if (valid) {
-          if (bL0 < 0) { bL0 = b; imL0 = im; }
-          else if (bL1 < 0) { bL1 = b; imL1 = im; }
-        }
-        const int mine = bi;
-        targmax(bs, bi);
-        if (valid && bi != 0x7fffffff) {
+        if (bL0 < 0) { bL0 = b; imL0 = im; }
+        else if (bL1 < 0) { bL1 = b; imL1 = im; }
+        wargmax(bs, bi);
+        if (bi != 0x7fffffff) {   // position of the deepest vertex, formed once by the body's own lane
           active_mask |= 1u << b;
-          const int win = __ffs(tballot(mine == bi)) - 1;   // the lane that holds the winner's position
-          const float wx = tshfl(bx[0], win), wy = tshfl(bx[1], win), wz = tshfl(bx[2], win);
-          if (lane == b) { a_x[0] = wx; a_x[1] = wy; a_x[2] = wz; a_d = -bs; a_v = bi; }
+          if (lt == b) {
+            const float4 hw = args.arr.hull[bi];
+            const float hv[3] = {hw.x, hw.y, hw.z};
+            float w[3];
+            matvec3(R, hv, w);
+            a_x[0] = r[0] + w[0]; a_x[1] = r[1] + w[1]; a_x[2] = r[2] + w[2] - hw.w;
+            a_d = -bs; a_v = bi;
+          }
         }
       }
-#if TREX_STAMPS
-      wave_cg2 += __builtin_amdgcn_s_memtime() - cg_t1;
-#endif
-      STAMP2(1);
-      const int n_active = __popc(active_mask);
+      int n_active = __popc(active_mask);
       int K = n_active > 0 ? maxc / n_active : 0;
       K = K > 4 ? 4 : (K < 1 ? 1 : K);
-      STAMP2(2);
-      if (!wave_any(n_active > 0 && K >= 2)) {
-        // fast path (one point per touching body in both envs of the wave - the standing case): contact
-        // slot c takes the c-th touching body; every lane finds its body and gathers its point at once
-        unsigned m = active_mask;
-        for (int i = 0; i < lane && m != 0u; i++) m &= m - 1u;
-        nc = min(n_active, maxc);
-        const int bsrc = m != 0u ? (__ffs(m) - 1) : 0;
-        const float gx = tshfl(a_x[0], bsrc), gy = tshfl(a_x[1], bsrc), gz = tshfl(a_x[2], bsrc), gd = tshfl(a_d, bsrc);
-        if (lane < nc) { cbody = bsrc; cx[0] = gx; cx[1] = gy; cx[2] = gz; cdist = gd; }
-        active_mask = 0u;
+      if (n_active > maxc) {
+        // more touching bodies than contact rows: keep the maxc bodies whose deepest vertex is deepest
+        // (ties -> lower body index), one point each; they stay in body order.
+        int rank = 0;
+        for (unsigned m = active_mask; m != 0u; m &= m - 1u) {
+          const int b2 = __ffs(m) - 1;
+          const float d2 = rl(a_d, b2);
+          rank += (d2 < a_d || (d2 == a_d && b2 < lt)) ? 1 : 0;
+        }
+        active_mask = (unsigned)__ballot(lt < 32 && ((active_mask >> bl) & 1u) && rank < maxc);
+        n_active = maxc;
       }
-      STAMP2(3);
-      while (wave_any(active_mask != 0u)) {
-#if TREX_STAMPS
-        dbg_bodies++;
-#endif
-        const bool valid = active_mask != 0u;
-        const int b = valid ? (__ffs(active_mask) - 1) : 0;
-        active_mask &= active_mask - 1u;
-        int sel[4] = {-1, -1, -1, -1};
-        float px[4][3], pd[4];
-        sel[0] = tshfl(a_v, b);
+      if (K < 2) {
+        // one point per touching body (the standing case): contact c is the c-th touching body's deepest vertex
+        const bool mine = lt < 32 && ((active_mask >> bl) & 1u);
+        const int slot = __popc(active_mask & ((1u << bl) - 1u));
+        if (mine) {
+          float *o = W.cpt[slot];
+          o[0] = __int_as_float(lt); o[1] = a_x[0]; o[2] = a_x[1]; o[3] = a_x[2]; o[4] = a_d;
+        }
+        nc = n_active;
+      } else {
+        for (unsigned am = active_mask; am != 0u; am &= am - 1u) {
+          const int b = __ffs(am) - 1;
+          int sel[4] = {-1, -1, -1, -1};
+          float px[4][3], pd[4];
+          sel[0] = rl(a_v, b);
 #pragma unroll
-        for (int c = 0; c < 3; c++) px[0][c] = tshfl(a_x[c], b);
-        pd[0] = tshfl(a_d, b);
-        int nsel = valid ? 1 : 0;
-        bool stop = !valid || K < 2;
-        if (wave_any(!stop)) {
+          for (int c = 0; c < 3; c++) px[0][c] = rl(a_x[c], b);
+          pd[0] = rl(a_d, b);
+          int nsel = 1;
           float Rb[9], rb[3];
 #pragma unroll
-          for (int c = 0; c < 9; c++) Rb[c] = tshfl(R[c], b);
+          for (int c = 0; c < 9; c++) Rb[c] = rl(R[c], b);
 #pragma unroll
-          for (int c = 0; c < 3; c++) rb[c] = tshfl(r[c], b);
-          const int v0 = tshfl(hull_v0, b), v1 = tshfl(hull_v1, b);
-          // this lane's candidates of body b: bit i <-> vertex v0 + lane + 32 i (in the margin during pass A)
+          for (int c = 0; c < 3; c++) rb[c] = rl(r[c], b);
+          const int v0 = rl(hull_v0, b), v1 = rl(hull_v1, b);
+          // this lane's candidates of body b: bit i <-> vertex v0 + lane + 64 i (in the margin during pass A)
           unsigned im;
-          // (a team without an active body in this trip has stop = true: it must not sweep body 0's hull)
-          const bool masked = stop || ((v1 - v0) <= 1024 && ((v1 - v0) <= SMALL_HULL || b == bL0 || b == bL1));
+          const bool masked = (v1 - v0) <= 2048 && ((v1 - v0) <= SMALL_HULL || b == bL0 || b == bL1);
           if ((v1 - v0) <= SMALL_HULL) {
-            const unsigned c0 = (unsigned)tshfl((int)cm0, b), c1 = (unsigned)tshfl((int)cm1, b), c2 = (unsigned)tshfl((int)cm2, b);
-            im = ((c0 >> lane) & 1u) | (((c1 >> lane) & 1u) << 1) | (((c2 >> lane) & 1u) << 2);
+            const unsigned c0 = rl(cm0, b), c1 = rl(cm1, b), c2 = rl(cm2, b);
+            im = (lt < 32) ? (((c0 >> bl) & 1u) | (((c2 >> bl) & 1u) << 1)) : ((c1 >> bl) & 1u);
           } else {
             im = (b == bL0) ? imL0 : ((b == bL1) ? imL1 : 0xffffffffu);
           }
-          if (!masked) im = 0xffffffffu;   // (a third large hull, or one beyond 1024 vertices: sweep it)
+          if (!masked) im = 0xffffffffu;   // (a third large hull, or one beyond 2048 vertices: sweep it)
           {
             const int o = sel[0] - v0;     // the deepest vertex is taken
-            if (lane == (o & 31) && (o >> 5) < 32) im &= ~(1u << (o >> 5));
+            if (lt == (o & 63) && (o >> 6) < 32) im &= ~(1u << (o >> 6));
           }
+          bool stop = false;
 #pragma unroll
           for (int pass = 1; pass < 4; pass++) {
-            if (!wave_any(!stop)) break;
-#if TREX_STAMPS
-            dbg_passes++;
-#endif
+            if (stop) break;
             float bs = -3.0e38f;
             int bi = 0x7fffffff;
             float ex = 0.f, ey = 0.f, flip = 1.f;
@@ -1009,7 +663,7 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
               flip = c3 > 0.f ? -1.f : 1.f;
             }
             float bx[3] = {0.f, 0.f, 0.f};
-            const int nit = (v1 - v0 - lane + TL - 1) / TL;   // strided vertices of this lane
+            const int nit = (v1 - v0 - lt + 63) / 64;   // strided vertices of this lane
             auto visit = [&](int v, const float4 h) {
               const float hv[3] = {h.x, h.y, h.z};
               float w[3];
@@ -1028,18 +682,15 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
               if (score > bs) { bs = score; bi = v; bx[0] = x0; bx[1] = x1; bx[2] = x2; }
             };
             if (masked) {
-              constexpr int UC = 4;   // candidates per trip: their loads are issued together
-              for (unsigned m = stop ? 0u : im; wave_any(m != 0u);) {
-#if TREX_STAMPS
-                dbg_trips++;
-#endif
+              constexpr int UC = 2;   // candidates per trip: their loads are issued together
+              for (unsigned m = im; __ballot(m != 0u) != 0ull;) {
                 int vi[UC];
                 float4 hc[UC];
 #pragma unroll
                 for (int u = 0; u < UC; u++) {
                   const int i = m != 0u ? (__ffs(m) - 1) : 32;
                   m &= m - 1u;            // (0 stays 0)
-                  vi[u] = i < nit ? v0 + lane + TL * i : -1;
+                  vi[u] = i < nit ? v0 + lt + 64 * i : -1;
                   hc[u] = args.arr.hull[vi[u] >= 0 ? vi[u] : v0];
                 }
 #pragma unroll
@@ -1047,475 +698,663 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
                   if (vi[u] >= 0) visit(vi[u], hc[u]);
               }
             } else {
-              for (int v = v0 + lane; !stop && v < v1; v += TL) visit(v, args.arr.hull[v]);
+              for (int v = v0 + lt; v < v1; v += 64) visit(v, args.arr.hull[v]);
             }
             const int mine = bi;
-            targmax(bs, bi);
+            wargmax(bs, bi);
             if (pass >= K || bi == 0x7fffffff || !(bs > 0.f)) stop = true;
-            const int win = __ffs(tballot(mine == bi && bi != 0x7fffffff)) - 1;
-            const float wx = tshfl(bx[0], win < 0 ? 0 : win), wy = tshfl(bx[1], win < 0 ? 0 : win), wz = tshfl(bx[2], win < 0 ? 0 : win);
             if (!stop) {
+              const int win = __ffsll((unsigned long long)__ballot(mine == bi)) - 1;   // the lane that holds the winner
               sel[pass] = bi;
-              px[pass][0] = wx; px[pass][1] = wy; px[pass][2] = wz;
-              pd[pass] = pos[2] + wz - floor_z;
+              px[pass][0] = rl(bx[0], win); px[pass][1] = rl(bx[1], win); px[pass][2] = rl(bx[2], win);
+              pd[pass] = pos[2] + px[pass][2] - floor_z;
               nsel = pass + 1;
             }
           }
-        }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          if (k < nsel && nc < maxc) {
-            if (lane == nc) { cbody = b; cx[0] = px[k][0]; cx[1] = px[k][1]; cx[2] = px[k][2]; cdist = pd[k]; }
-            nc++;
-          }
-        }
-      }
-    }
-
-    STAMP2(4);
-#if TREX_STAMPS
-    wave_cg += __builtin_amdgcn_s_memtime() - cg_t0;
-#endif
-    STAMP(8);
-    WPH(1);
-#if TREX_PRIO_MODE == 2
-    {   // wave-level priority for the rest of the substep: total contact rows of the two envs
-      const int tot = __builtin_amdgcn_readlane(nc, 0) + __builtin_amdgcn_readlane(nc, 32);
-      if (tot >= 12) __builtin_amdgcn_s_setprio(3);
-      else if (tot >= 8) __builtin_amdgcn_s_setprio(2);
-      else if (tot >= 4) __builtin_amdgcn_s_setprio(1);
-      else __builtin_amdgcn_s_setprio(0);
-    }
-#endif
-    // ---- constraint solve: projected Gauss-Seidel in DELASSUS (residual) form, one env at a time on all
-    // 64 lanes. Rows of an env: 25 motor rows (joint j, with the joint's limit row riding on the same lane)
-    // and 3 rows per contact point (normal z, friction x, friction y). Each row s lives on ONE lane and keeps
-    //     y_s = rhs_s - (J_s dv) / diag_s            (its unclamped Gauss-Seidel increment)
-    // so a row visit is  nl = clamp(lam_r + y_r); d = nl - lam_r; lam_r = nl;  y_s += B_sr d  for all s, with
-    // B_sr = -(J_s M^-1 J_r^T)/diag_s (B_rr = -1) - the same iteration as Bullet's dv form (and the oracle's),
-    // but the row's impulse change reaches the other rows as ONE v_readlane (SGPR broadcast) + ONE packed fma
-    // per lane instead of a 32-lane reduction per row: 6-7 instructions per env-row instead of 12 for a
-    // contact row, and a light env no longer walks its wave partner's rows. y (not z = lam + y) is what is
-    // accumulated: it is small where lam is large, and the rounding of a row's own update stays in y.
-    // Rows -> lanes (the same for both envs of the wave; the per-lane inputs of env 1 are brought down
-    // with v_permlane32_swap): motor row j on lane j (1..25); contact row k = 3c+a on lane 32+k for k < 32
-    // and on the seven lanes left in the lower half (0, 26..31) for k = 32..38: 25 + 3 x 13 = 64 rows, one
-    // per lane - which is where the budget of 13 contact points per env comes from.
-    // B comes from the factorisation M^-1 = A^T B A: every row carries a descriptor (chain nodes ca[d],
-    // entries u[d], base force r0; zc = u/D, z0 = I0^-1 r0) and
-    //     J_s M^-1 J_r^T = r0_s . z0_r + sum_d [ca_s[d] == ca_r[d]] u_s[d] zc_r[d].
-    // Motor columns go to LDS (read back one per motor row, and by the dynamic limit rows), contact columns
-    // into registers (static index).
-    float dv = 0.f, nimp = 0.f;
-    const int tid = threadIdx.x;
-    // motor rows of both envs: staged once, so that the factorisation's per-lane column data (Aanc, Z, A0,
-    // g) is dead before the solves
-    __syncthreads();
-    {
-      RowStage &S_ = W.u.rows;
-      if (lane >= 1 && lane <= NJMAX) {
-        const int row = team * NJMAX + lane - 1;
-        const bool jn = is_joint;
-        int ca[MAXD];
-#pragma unroll
-        for (int d = 0; d < MAXD; d++) ca[d] = jn ? anc[d] : -1;
-        S_.col[row][0] = make_float4(__int_as_float(ca[0]), __int_as_float(ca[1]), __int_as_float(ca[2]), __int_as_float(ca[3]));
-        S_.col[row][1] = make_float4(__int_as_float(ca[4]), __int_as_float(ca[5]), jn ? Z[0] : 0.f, jn ? Z[1] : 0.f);
-        S_.col[row][2] = make_float4(jn ? Z[2] : 0.f, jn ? Z[3] : 0.f, jn ? Z[4] : 0.f, jn ? Z[5] : 0.f);
-        S_.col[row][3] = make_float4(jn ? g[0] : 0.f, jn ? g[1] : 0.f, jn ? g[2] : 0.f, jn ? g[3] : 0.f);
-        S_.col[row][4] = make_float4(jn ? g[4] : 0.f, jn ? g[5] : 0.f, 0.f, 0.f);
-        float *o = S_.own[row];
-#pragma unroll
-        for (int d = 0; d < MAXD; d++) { o[d] = jn ? Aanc[d] : 0.f; o[6 + d] = jn ? A0[d] : 0.f; }
-        o[12] = jn ? inv_mdiag : 0.f; o[13] = jn ? mot_rhs : 0.f;
-      }
-    }
-    auto krow_lane = [](int k) { return k < 32 ? 32 + k : (k == 32 ? 0 : k - 7); };   // lane of contact row k
-#pragma unroll 1
-    for (int e_ = 0; e_ < 2; e_++) {
-      int e = e_;
-      asm volatile("" : "+s"(e));   // one copy of the solve in the instruction cache, not two
-      // -- contact rows of each team's points: lane c owns point c and walks its body's chain for the
-      //    three directions; per lane, no reductions. (Both teams walk; team e's result is staged.)
-      const int ncE = __builtin_amdgcn_readlane(nc, 32 * e);
-      const unsigned lmE = (unsigned)__builtin_amdgcn_readlane((int)lim_mask, 32 * e);
-      const float muE = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mu), 32 * e));
-      // per-lane inputs of the motor rows, on lanes 0..31 for either env
-      auto pick = [&](float x) {
-        const unsigned u = __float_as_uint(x);
-        const auto r2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-        return __uint_as_float(e ? r2[1] : r2[0]);
-      };
-      const float mhi = pick(mot_hi), ldir = pick(lim_dir), lr = pick(lim_rhs - lim_dir * mot_rhs), mdg = pick(mdiag);
-      // -- contact rows of env e: walk (both teams walk, team e stages) - skipped for an airborne env
-      __syncthreads();
-      if (ncE > 0) {
-        // Every number of a row descriptor goes to the LDS stage the moment it is known (team e's point
-        // lanes write, the others only walk): nothing but the three running forces p[a] is carried.
-        const bool has = lane < nc;
-        const bool st = (team == e) && lane < MAXC;
-        int anc_w[MAXD];   // re-read (L2-resident model): not carried across contact generation and the other env's solve
-        {
-          const TrexDeviceModel *Mi = Mo();
-#pragma unroll
-          for (int d = 0; d < MAXD; d++) anc_w[d] = is_body ? Mi->anc[d][lane] : -1;
-        }
-        float *colf = reinterpret_cast<float *>(W.u.rows.col[CROW0 + 3 * (st ? lane : 0)]);   // 20 words per row
-        float *ownf = W.u.rows.own[CROW0 + 3 * (st ? lane : 0)];                               // 15 words per row
-        // updated body velocities (after the unconstrained step) for the row right-hand sides
-        float nvel[6];
-        body_velocities(nw, nv, nqd, nvel);
-        float vb[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) vb[k] = tshfl(nvel[k], cbody);
-        float p[3][6], diag[3] = {0.f, 0.f, 0.f};
-        const float dirs[3][3] = {{0.f, 0.f, 1.f}, {1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}};
-        float po[3], xrel[3];   // po: the point the forces p[a] refer to (body origin first, then up the chain)
-#pragma unroll
-        for (int k = 0; k < 3; k++) { po[k] = tshfl(r[k], cbody); xrel[k] = cx[k] - po[k]; }
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-          float xd[3];
-          cross3(xrel, dirs[a], xd);
-#pragma unroll
-          for (int k = 0; k < 3; k++) { p[a][k] = -xd[k]; p[a][3 + k] = -dirs[a][k]; }
-        }
-#pragma unroll
-        for (int d = MAXD; d >= 1; d--) {
-          int ca = -1;
-          float ua[3] = {0.f, 0.f, 0.f}, zc[3] = {0.f, 0.f, 0.f};
-          if (d <= maxdepth) {
-            const int ab = tshfl(anc_w[d - 1], cbody);
-            ca = has ? ab : -1;
-            const int src = ab < 0 ? 0 : ab;
-            float aa[3], Uda[6], ra[3];
-#pragma unroll
-            for (int k = 0; k < 3; k++) { aa[k] = tshfl(S[k], src); ra[k] = tshfl(r[k], src); }
-#pragma unroll
-            for (int k = 0; k < 6; k++) Uda[k] = tshfl(Ud[k], src);
-            const float invDa = tshfl(invD, src);
-            if (has && ab >= 0) {
-              float dd[3];
-#pragma unroll
-              for (int k = 0; k < 3; k++) { dd[k] = po[k] - ra[k]; po[k] = ra[k]; }
-#pragma unroll
-              for (int a = 0; a < 3; a++) {
-                float dxf[3];
-                cross3(dd, p[a] + 3, dxf);
-#pragma unroll
-                for (int k = 0; k < 3; k++) p[a][k] += dxf[k];
-                ua[a] = -dot3(aa, p[a]);
-                zc[a] = ua[a] * invDa;
-                diag[a] += ua[a] * ua[a] * invDa;
-#pragma unroll
-                for (int k = 0; k < 6; k++) p[a][k] += Uda[k] * ua[a];
+          for (int k = 0; k < 4; k++) {
+            if (k < nsel && nc < maxc) {
+              if (lt == 0) {
+                float *o = W.cpt[nc];
+                o[0] = __int_as_float(b); o[1] = px[k][0]; o[2] = px[k][1]; o[3] = px[k][2]; o[4] = pd[k];
               }
-            }
-          }
-          if (st) {
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-              colf[20 * a + d - 1] = __int_as_float(ca);
-              colf[20 * a + 6 + d - 1] = zc[a];
-              ownf[15 * a + d - 1] = ua[a];
+              nc++;
             }
           }
         }
-        float pvel[3], wxx[3];
-        cross3(vb, xrel, wxx);   // body velocity is about the body origin
-        float I0l[21];
+      }
+    }
+    nc = uni(nc);
+#if TREX_PRIO_MODE == 2
+    set_priority(nc);
+#endif
+    STAMP(1);
+    RELANE();
+    RETREE();
+    REAXIS();
+
+    // ================================================================ tree dynamics
+    // ---- rigid-body spatial inertia about the body origin, bias force (both straight to the body's LDS slot:
+    // the tip-to-base pass works on LDS-resident inertias), velocity-product acceleration cv (registers)
+    float cv[6];
+    {
+      Sym6 IA;
+      float pA[6];
+      const float qd = W.st[ST_QD][bl];
+      // spatial velocity of every body ABOUT ITS OWN ORIGIN for the base twist and the joint rates
+      float vel[6];
 #pragma unroll
-        for (int k = 0; k < 21; k++) I0l[k] = W.i0inv[team][k];
+      for (int c = 0; c < 3; c++) { vel[c] = bw[c]; vel[3 + c] = bv[c]; }
+      for (int d = 1; d <= maxdepth; d++) {
+        float pv[6];
 #pragma unroll
-        for (int k = 0; k < 3; k++) pvel[k] = vb[3 + k] + wxx[k];
+        for (int c = 0; c < 6; c++) pv[c] = wshfl(vel[c], psrc);
+        if (depth == d) {
+          float wxd[3];
+          cross3(pv, dpar, wxd);   // velocity of the parent-body point at this body's origin
 #pragma unroll
-        for (int a = 0; a < 3; a++) {
-          float rhs0[6], z0[6], dxf[3];
-          cross3(po, p[a] + 3, dxf);   // on to the base origin O
-#pragma unroll
-          for (int k = 0; k < 3; k++) p[a][k] += dxf[k];
-#pragma unroll
-          for (int k = 0; k < 6; k++) rhs0[k] = -p[a][k];
-          inv21_mul(I0l, rhs0, z0);
-          diag[a] += dot6(rhs0, z0);
-          const float inv = has ? 1.0f / diag[a] : 0.f;
-          float tv = 0.f;
-          if (a == 0) tv = (cdist > 0.f) ? -cdist * inv_dt : -cdist * cerp * inv_dt;
-          const float rhs = (tv - dot3(dirs[a], pvel)) * inv;
-          if (st) {
-#pragma unroll
-            for (int k = 0; k < 6; k++) { colf[20 * a + 12 + k] = has ? z0[k] : 0.f; ownf[15 * a + 6 + k] = has ? rhs0[k] : 0.f; }
-            colf[20 * a + 18] = 0.f; colf[20 * a + 19] = 0.f;
-            ownf[15 * a + 12] = inv; ownf[15 * a + 13] = has ? rhs : 0.f; ownf[15 * a + 14] = 0.f;
-          }
-        }
-      } else if (team == e && lane < MAXC) {
-        RowStage &S_ = W.u.rows;
-        const float m1 = __int_as_float(-1);
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-          const int row = CROW0 + 3 * lane + a;
-          S_.col[row][0] = make_float4(m1, m1, m1, m1);
-          S_.col[row][1] = make_float4(m1, m1, 0.f, 0.f);
-          S_.col[row][2] = make_float4(0.f, 0.f, 0.f, 0.f);
-          S_.col[row][3] = make_float4(0.f, 0.f, 0.f, 0.f);
-          S_.col[row][4] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-          for (int k = 0; k < 15; k++) S_.own[row][k] = 0.f;
+          for (int c = 0; c < 3; c++) { vel[c] = pv[c] + Sa[c] * qd; vel[3 + c] = pv[3 + c] + wxd[c]; }
         }
       }
-      STAMP(9);
-      if (team == e) {
-        RowStage &S_ = W.u.rows;
-        if (lane == 31) {   // the null record
-          const float m1 = __int_as_float(-1);
-          S_.col[NREC - 1][0] = make_float4(m1, m1, m1, m1);
-          S_.col[NREC - 1][1] = make_float4(m1, m1, 0.f, 0.f);
-          S_.col[NREC - 1][2] = make_float4(0.f, 0.f, 0.f, 0.f);
-          S_.col[NREC - 1][3] = make_float4(0.f, 0.f, 0.f, 0.f);
-          S_.col[NREC - 1][4] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const TrexDeviceModel *Mi = Mo();
+      float comb[3], inb[6];
+      const float mscale = args.arr.mass_scale[(size_t)env * TL + bl];
+      const float mass = Mi->mass[bl] * mscale;
 #pragma unroll
-          for (int k = 0; k < 15; k++) S_.own[NREC - 1][k] = 0.f;
-        }
-      }
-      __syncthreads();
-      // -- this lane's row
-      int row0;
-      if (tid >= 1 && tid <= NJMAX) row0 = e * NJMAX + tid - 1;
-      else if (tid >= 32) row0 = CROW0 + (tid - 32);
-      else row0 = CROW0 + 32 + (tid == 0 ? 0 : tid - 25);   // lanes 0, 26..31 -> contact rows 32..38
-      int ca0[MAXD];
-      float u0[MAXD], r00[6], zc0[MAXD], z00[6], inv0, y, lam = 0.f;
+      for (int c = 0; c < 3; c++) comb[c] = Mi->com[c][bl];
+#pragma unroll
+      for (int c = 0; c < 6; c++) inb[c] = Mi->inertia[c][bl];
+      const float grav = Mi->prm[TP_GRAVITY], kdamp = Mi->prm[TP_LINK_DAMPING];
+      float comw[3], Icw[6];   // comw = COM offset from the body origin, world axes
       {
-        const float *c = reinterpret_cast<const float *>(W.u.rows.col[row0]);
-        const float *o = W.u.rows.own[row0];
+        matvec3(R, comb, comw);
+        // Ic_world = R Ib R^T (symmetric)
+        float t[9];
+        const float Ib[9] = {inb[0], inb[1], inb[2], inb[1], inb[3], inb[4], inb[2], inb[4], inb[5]};
+        matmul3(R, Ib, t);
+        const int ia[6] = {0, 0, 0, 1, 1, 2}, ib[6] = {0, 1, 2, 1, 2, 2};
 #pragma unroll
-        for (int d = 0; d < MAXD; d++) { ca0[d] = __float_as_int(c[d]); zc0[d] = c[6 + d]; z00[d] = c[12 + d]; u0[d] = o[d]; r00[d] = o[6 + d]; }
-        inv0 = o[12]; y = o[13];
+        for (int k = 0; k < 6; k++)
+          Icw[k] = mscale * (t[3 * ia[k]] * R[3 * ib[k]] + t[3 * ia[k] + 1] * R[3 * ib[k] + 1] + t[3 * ia[k] + 2] * R[3 * ib[k] + 2]);
       }
-      // B entries of this lane's row against column r: the column's descriptor (ca, zc, z0: 18 words) sits in
-      // the registers of the lane that owns row r and is broadcast with v_readlane into SGPRs - no LDS round
-      // trip per column. Unused chain slots hold u = zc = 0, so a -1 == -1 match adds nothing.
-      auto bcast_i = [&](int v, int L) { return __builtin_amdgcn_readlane(v, L); };
-      auto bcast_f = [&](float v, int L) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), L)); };
-      // -- motor columns -> registers (and LDS for the dynamic limit rows); column j is row lane j
-      float Bm[NJMAX];
+      {
+        const float cc = dot3(comw, comw);
+        IA.A[0] = Icw[0] + mass * (cc - comw[0] * comw[0]);
+        IA.A[1] = Icw[1] - mass * comw[0] * comw[1];
+        IA.A[2] = Icw[2] - mass * comw[0] * comw[2];
+        IA.A[3] = Icw[3] + mass * (cc - comw[1] * comw[1]);
+        IA.A[4] = Icw[4] - mass * comw[1] * comw[2];
+        IA.A[5] = Icw[5] + mass * (cc - comw[2] * comw[2]);
+        // B = m * [c]x
+        IA.B[0] = 0.f;              IA.B[1] = -mass * comw[2];  IA.B[2] = mass * comw[1];
+        IA.B[3] = mass * comw[2];   IA.B[4] = 0.f;              IA.B[5] = -mass * comw[0];
+        IA.B[6] = -mass * comw[1];  IA.B[7] = mass * comw[0];   IA.B[8] = 0.f;
+        IA.C[0] = mass; IA.C[1] = 0.f; IA.C[2] = 0.f; IA.C[3] = mass; IA.C[4] = 0.f; IA.C[5] = mass;
+      }
+      if (!is_body) {
 #pragma unroll
-      for (int j = 1; j <= NJMAX; j++) {
-        float a0_ = 0.f;
+        for (int k = 0; k < 6; k++) { IA.A[k] = (k == 0 || k == 3 || k == 5) ? 1.f : 0.f; IA.C[k] = IA.A[k]; }
 #pragma unroll
-        for (int d = 0; d < 6; d++) a0_ = __builtin_fmaf(r00[d], bcast_f(z00[d], j), a0_);
+        for (int k = 0; k < 9; k++) IA.B[k] = 0.f;
+      }
+      {
+        float h[6];
+        sym6_mul(IA, vel, h);
+        // v x* h
+        float a[3], b[3], c[3];
+        cross3(vel, h, a); cross3(vel + 3, h + 3, b); cross3(vel, h + 3, c);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { pA[k] = a[k] + b[k]; pA[3 + k] = c[k]; }
+        float f[3] = {0.f, 0.f, -mass * grav}, n[3] = {0.f, 0.f, 0.f};
+        if (kdamp > 0.f) {
+          float vc[3], wxc[3], Iw[3];
+          cross3(vel, comw, wxc);
+#pragma unroll
+          for (int k = 0; k < 3; k++) vc[k] = vel[3 + k] + wxc[k];
+          const float sv = sqrtf(dot3(vc, vc)), sw = sqrtf(dot3(vel, vel));
+          sym3_mul(Icw, vel, Iw);
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            f[k] -= mass * vc[k] * (kdamp + kdamp * sv);
+            n[k] -= Iw[k] * (kdamp + kdamp * sw);
+          }
+        }
+        float cxf[3];
+        cross3(comw, f, cxf);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { pA[k] -= n[k] + cxf[k]; pA[3 + k] -= f[k]; }
+        // c = vel x (S qd), S = [Sa; 0]
+        float sq[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) sq[k] = Sa[k] * qd;
+        float x0[3], x2[3];
+        cross3(vel, sq, x0); cross3(vel + 3, sq, x2);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { cv[k] = x0[k]; cv[3 + k] = x2[k]; }
+        if (!is_body) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) { pA[k] = 0.f; cv[k] = 0.f; }
+        }
+      }
+      if (is_body) {
+        float *o = W.u.aba[bl];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { o[k] = IA.A[k]; o[15 + k] = IA.C[k]; o[21 + k] = pA[k]; }
+#pragma unroll
+        for (int k = 0; k < 9; k++) o[6 + k] = IA.B[k];
+      }
+    }
+    __syncthreads();
+    STAMP(2);
+    RELANE();
+    RETREE();
+    REAXIS();
+
+    // ---- ABA pass 2 (tip to base) on LDS-resident inertias: slot b of W.u.aba holds body b's articulated
+    // inertia (21) and bias force (6) about its own origin. At level d the lanes AT depth d take their slot -
+    // complete by then -, form U, 1/D, u (which go to the body record: pass 3 and the row walks read them there),
+    // remove the joint's freedom, shift to the parent's origin and put the result back; the lanes at depth d-1
+    // then add their children's slots to their own. Nothing of this is carried in registers between levels.
+    {
+      const TrexDeviceModel *Mi = Mo();
+      const float tau_j = -Mi->damp[bl] * W.st[ST_QD][bl];  // explicit joint damping torque
+      for (int d = maxdepth; d >= 1; d--) {
+        if (depth == d) {
+          float *o = W.u.aba[bl];
+          Sym6 IA;
+          float pA[6];
+#pragma unroll
+          for (int k = 0; k < 6; k++) { IA.A[k] = o[k]; IA.C[k] = o[15 + k]; pA[k] = o[21 + k]; }
+#pragma unroll
+          for (int k = 0; k < 9; k++) IA.B[k] = o[6 + k];
+          float U[6];   // U = IA S, S = [Sa; 0]
+          sym3_mul(IA.A, Sa, U);
+          U[3] = IA.B[0] * Sa[0] + IA.B[3] * Sa[1] + IA.B[6] * Sa[2];
+          U[4] = IA.B[1] * Sa[0] + IA.B[4] * Sa[1] + IA.B[7] * Sa[2];
+          U[5] = IA.B[2] * Sa[0] + IA.B[5] * Sa[1] + IA.B[8] * Sa[2];
+          const float invD = 1.0f / dot3(Sa, U);
+          const float u = tau_j - dot3(Sa, pA);
+          {
+            float4 *rec = &W.body[BREC * bl];
+            rec[0] = make_float4(Sa[0], Sa[1], Sa[2], invD);
+            rec[2] = make_float4(U[0] * invD, U[1] * invD, U[2] * invD, U[3] * invD);
+            rec[3] = make_float4(U[4] * invD, U[5] * invD, __int_as_float(psrc + 256 * depth), u * invD);
+          }
+          {   // pa = pA + Ia c + U u / D with Ia c = IA c - U (U.c) / D
+            float Ic[6];
+            sym6_mul(IA, cv, Ic);
+            const float coef = (u - dot6(U, cv)) * invD;
+#pragma unroll
+            for (int k = 0; k < 6; k++) pA[k] += Ic[k] + U[k] * coef;
+          }
+          sym6_rank1_sub(IA, U, invD);
+          // shift both to the parent's origin (this origin = parent origin + d, d = dpar):
+          //   n' = n + d x f,  B' = B + [d]x C,  A' = A + X^T + X', X = [d]x B^T, X' = [d]x B'^T
+          {
+            float t[3];
+            cross3(dpar, pA + 3, t);
+#pragma unroll
+            for (int k = 0; k < 3; k++) pA[k] += t[k];
+            const int sidx[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+#pragma unroll
+            for (int i = 0; i < 3; i++) {   // A_ij += X_ji = (d x row i of B)_j
+              cross3(dpar, IA.B + 3 * i, t);
+#pragma unroll
+              for (int j = i; j < 3; j++) IA.A[sidx[i][j]] += t[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 3; j++) {   // column j of [d]x C = d x (column j of C)
+              const float cj[3] = {IA.C[sidx[0][j]], IA.C[sidx[1][j]], IA.C[sidx[2][j]]};
+              cross3(dpar, cj, t);
+#pragma unroll
+              for (int i = 0; i < 3; i++) IA.B[3 * i + j] += t[i];
+            }
+#pragma unroll
+            for (int j = 0; j < 3; j++) {   // A_ij += X'_ij = (d x row j of B')_i
+              cross3(dpar, IA.B + 3 * j, t);
+#pragma unroll
+              for (int i = 0; i <= j; i++) IA.A[sidx[i][j]] += t[i];
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 6; k++) { o[k] = IA.A[k]; o[15 + k] = IA.C[k]; o[21 + k] = pA[k]; }
+#pragma unroll
+          for (int k = 0; k < 9; k++) o[6 + k] = IA.B[k];
+        }
+        __syncthreads();
+        if (depth == d - 1) {
+          float acc[27];
+          float *o = W.u.aba[bl];
+#pragma unroll
+          for (int k = 0; k < 27; k++) acc[k] = o[k];
+          const TrexDeviceModel *Mj = Mo();
+#pragma unroll 1
+          for (int kc = 0; kc < MAXCH; kc++) {   // children in fixed order (one child's 27 words in flight at a time)
+            const int ch = Mj->child[kc][bl];
+            if (ch >= 0) {
+              const float *c = W.u.aba[ch];
+#pragma unroll
+              for (int k = 0; k < 27; k++) acc[k] += c[k];
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 27; k++) o[k] = acc[k];
+        }
+        __syncthreads();
+      }
+      if (lt < TL && !is_joint) {   // base and unused lanes: inert records
+        float4 *rec = &W.body[BREC * lt];
+        rec[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rec[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rec[3] = make_float4(0.f, 0.f, __int_as_float(psrc + 256 * (depth < 0 ? 255 : depth)), 0.f);
+      }
+    }
+    STAMP(3);
+    RELANE();
+    RETREE();
+    REAXIS();
+
+    // ---- floating base: a0 = -(IA_0)^-1 pA_0; the inverse is wave-uniform (SGPRs)
+    float I0inv[21], a0[6];
+    {
+      const float *o = W.u.aba[0];   // every lane reads the same words: LDS broadcast
+      Sym6 I0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) { I0.A[k] = o[k]; I0.C[k] = o[15 + k]; }
+#pragma unroll
+      for (int k = 0; k < 9; k++) I0.B[k] = o[6 + k];
+      float p0[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) p0[k] = -o[21 + k];
+      float full[36], inv_l[21];
+      sym6_full(I0, full);
+      spd6_inverse(full, inv_l);
+#pragma unroll
+      for (int k = 0; k < 21; k++) I0inv[k] = uni(inv_l[k]);
+      inv21_mul(I0inv, p0, a0);
+#pragma unroll
+      for (int k = 0; k < 6; k++) a0[k] = uni(a0[k]);
+    }
+    // ---- ABA pass 3 (base to tip): accelerations; qdd = (u - U.a) / D = u/D - (U/D).a from the body record
+    float qdd = 0.f;
+    {
+      const float4 q2 = W.body[BREC * bl + 2], q3 = W.body[BREC * bl + 3];
+      const float Ud[6] = {q2.x, q2.y, q2.z, q2.w, q3.x, q3.y};
+      float acc[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) acc[k] = a0[k];
+      for (int d = 1; d <= maxdepth; d++) {
+        float pa[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) pa[k] = wshfl(acc[k], psrc);
+        if (depth == d) {
+          float axd[3];
+          cross3(pa, dpar, axd);   // parent acceleration seen at this body's origin
+#pragma unroll
+          for (int k = 0; k < 3; k++) pa[3 + k] += axd[k];
+#pragma unroll
+          for (int k = 0; k < 6; k++) pa[k] += cv[k];
+          qdd = q3.w - dot6(Ud, pa);
+#pragma unroll
+          for (int k = 0; k < 3; k++) acc[k] = pa[k] + Sa[k] * qdd;
+#pragma unroll
+          for (int k = 3; k < 6; k++) acc[k] = pa[k];
+        }
+      }
+    }
+    // ---- unconstrained velocity update
+    float nw[3], nv[3];
+    {
+      const float vmax = M->prm[TP_MAX_COORD_VEL];
+      float wxv[3];
+      cross3(bw, bv, wxv);
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        nw[k] = uni(fminf(fmaxf(bw[k] + a0[k] * dt, -vmax), vmax));
+        nv[k] = uni(fminf(fmaxf(bv[k] + (a0[3 + k] + wxv[k]) * dt, -vmax), vmax));
+      }
+      const float nqd = is_joint ? fminf(fmaxf(W.st[ST_QD][bl] + qdd * dt, -vmax), vmax) : 0.f;
+      // ---- the last thing the row walks need of a body: its updated joint rate
+      if (lt < TL) {
+        reinterpret_cast<float *>(&W.body[BREC * lt + 1])[3] = nqd;
+        W.st[ST_NQD][lt] = nqd;
+      }
+      if (DEBUG && args.debug && blockIdx.x == 0) {
+        float *D = args.debug;
+        if (lt < TL) { D[lt] = qdd; D[64 + lt] = nqd; }
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+          if (lt == k) D[32 + k] = a0[k];
+        if (lt == 0) {
+          for (int k = 0; k < 3; k++) { D[64 + nb + k] = nw[k]; D[64 + nb + 3 + k] = nv[k]; }
+        }
+      }
+    }
+    __syncthreads();
+    STAMP(4);
+    RELANE();
+
+    // ================================================================ constraint rows
+    // Rows -> lanes: motor row j on lane j (1..25, joint j's limit row riding on it); contact row k = 3 s + a
+    // of point SLOT s (a: normal z, friction x, friction y) on lane 26 + k for k < 38 and on lane 0 for k = 38.
+    // The nc points of this substep take the LAST nc slots (slot = MAXC - nc + contact number), so that a
+    // sweep is one jump into the unrolled chain of point blocks and no per-point branch.
+    const int s0 = uni(MAXC - nc);                               // first slot in use
+    bool mlane, mrow;                                            // motor-row lane; live motor row
+    int cdir;
+#define REROW() do { mlane = lt >= 1 && lt <= NJMAX; mrow = mlane && lt < nb; cdir = mlane ? 0 : (lt == 0 ? 2 : (lt - CLANE0) % 3); } while (0)
+    REROW();
+    // Every row walks its chain to the base ONCE: the generalised force J^T is pushed through the ABA
+    // factorisation (u_a = -a_a . n, p += (U/D)_a u_a), which yields the row's column of A (u), the same
+    // divided by D (zc), the base wrench r0 and z0 = I0^-1 r0 - and, for a contact row, the plain Jacobian
+    // entries for J.v on the way. A motor row is the unit force on its own joint: u = 1 at its own level.
+    // ca0: the chain, 5 bits per level (depth-1 ancestor in the low bits, 0 = none): two rows share the joints
+    // of their common prefix, so "same joint at level d" is "the lowest differing bit lies above field d"
+    unsigned ca0 = 0u;
+    static_assert(5 * MAXD <= 32 && NJMAX < 32, "chain packs into one register");
+    float u0[MAXD], zc0[MAXD], r00[6], z00[6], inv0 = 0.f, y = 0.f;
+    float mhi = 0.f, ldir = 0.f, lr = 0.f;
+    {
+      const int cslot = mlane ? 0 : (lt == 0 ? MAXC - 1 : (lt - CLANE0) / 3);
+      const bool crow = !mlane && cslot >= s0;                   // live contact row
+      float cx[3] = {0.f, 0.f, 0.f}, cdist = 0.f;
+      int cb = mrow ? lt : 0;
+      if (crow) {
+        const float *cp = W.cpt[cslot - s0];
+        cb = __float_as_int(cp[0]); cx[0] = cp[1]; cx[1] = cp[2]; cx[2] = cp[3]; cdist = cp[4];
+      }
+      const float dir[3] = {cdir == 1 ? 1.f : 0.f, cdir == 2 ? 1.f : 0.f, cdir == 0 ? 1.f : 0.f};
+      float p[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, po[3];
+      {
+        const float4 q1 = W.body[BREC * cb + 1];
+        po[0] = q1.x; po[1] = q1.y; po[2] = q1.z;
+      }
+      if (crow) {
+        const float xrel[3] = {cx[0] - po[0], cx[1] - po[1], cx[2] - po[2]};
+        float xd[3];
+        cross3(xrel, dir, xd);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { p[k] = -xd[k]; p[3 + k] = -dir[k]; }
+      }
+      const bool live = mrow || crow;
+      float diag = 0.f, jv = 0.f;
+      int cur = cb;
+#pragma unroll
+      for (int d = MAXD; d >= 1; d--) {
+        u0[d - 1] = 0.f; zc0[d - 1] = 0.f;
+        if (d <= maxdepth) {
+          const float4 q0 = W.body[BREC * cur], q1 = W.body[BREC * cur + 1], q2 = W.body[BREC * cur + 2], q3 = W.body[BREC * cur + 3];
+          const int lk = __float_as_int(q3.z);
+          if (live && (lk >> 8) == d) {
+            const float aa[3] = {q0.x, q0.y, q0.z}, ra[3] = {q1.x, q1.y, q1.z};
+            const float Uda[6] = {q2.x, q2.y, q2.z, q2.w, q3.x, q3.y};
+            float dd[3], dxf[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { dd[k] = po[k] - ra[k]; po[k] = ra[k]; }
+            cross3(dd, p + 3, dxf);
+#pragma unroll
+            for (int k = 0; k < 3; k++) p[k] += dxf[k];
+            const float ua = (mlane && cur == lt) ? 1.f : -dot3(aa, p);
+            const float zc = ua * q0.w;
+            diag += ua * zc;
+#pragma unroll
+            for (int k = 0; k < 6; k++) p[k] += Uda[k] * ua;
+            ca0 |= (unsigned)cur << (5 * (d - 1)); u0[d - 1] = ua; zc0[d - 1] = zc;
+            if (crow) {   // plain Jacobian entry of joint `cur`: a . ((x - r_a) x dir)
+              const float xr[3] = {cx[0] - ra[0], cx[1] - ra[1], cx[2] - ra[2]};
+              float xd[3];
+              cross3(xr, dir, xd);
+              jv += dot3(aa, xd) * q1.w;
+            }
+            cur = lk & 255;
+          }
+        }
+      }
+      {
+        float dxf[3];
+        cross3(po, p + 3, dxf);   // on to the base origin O
+#pragma unroll
+        for (int k = 0; k < 3; k++) p[k] += dxf[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 6; k++) r00[k] = live ? -p[k] : 0.f;
+      inv21_mul(I0inv, r00, z00);
+      diag += dot6(r00, z00);
+      inv0 = live ? 1.0f / diag : 0.f;
+      const TrexDeviceModel *Mi = Mo();
+      if (crow) {
+        const float cerp = Mi->prm[TP_CONTACT_ERP];
+        float tv = 0.f;
+        if (cdir == 0) tv = (cdist > 0.f) ? -cdist * inv_dt : -cdist * cerp * inv_dt;
+        float wxx[3];
+        cross3(nw, cx, wxx);
+        const float pv[3] = {nv[0] + wxx[0], nv[1] + wxx[1], nv[2] + wxx[2]};
+        y = (tv - (jv + dot3(dir, pv))) * inv0;
+      }
+      if (mrow) {
+        const float erp = Mi->prm[TP_ERP], kp = Mi->prm[TP_MOTOR_KP], kd = Mi->prm[TP_MOTOR_KD];
+        const float max_imp = Mi->motor_max_impulse;
+        const float q = W.st[ST_Q][bl], nqd = W.st[ST_NQD][bl], target = W.st[ST_TARGET][bl];
+        W.st[ST_MDG][bl] = diag;
+        // btMultiBodyJointMotor velocity target: kp*(target-q)/dt + qd + kd*(0-qd), minus current qd
+        y = (kp * (target - q) * inv_dt + kd * (0.f - nqd)) * inv0;
+        mhi = motors_on ? max_imp : 0.f;
+        const float q_lo = Mi->lower[bl], q_hi = Mi->upper[bl];
+        float pen = 0.f;
+        if (q - q_lo <= 0.f) { pen = q - q_lo; ldir = 1.f; }
+        else if (q_hi - q <= 0.f) { pen = q_hi - q; ldir = -1.f; }
+        const float lim_rhs = (-pen * erp * inv_dt - ldir * nqd) * inv0;
+        lr = lim_rhs - ldir * y;
+      }
+    }
+    const unsigned lim_mask = (unsigned)__ballot(ldir != 0.f);
+    __syncthreads();   // the body records are dead: the z0 stash may overwrite them
+    {
+      float *zs = reinterpret_cast<float *>(W.body);
+#pragma unroll
+      for (int k = 0; k < 6; k++) zs[64 * k + lt] = z00[k];
+    }
+    STAMP(5);
+    RELANE();
+
+    // ---- B entries of this lane's row against every column: B_sr = -(J_s M^-1 J_r^T) / diag_s with
+    //     J_s M^-1 J_r^T = r0_s . z0_r + sum_d [ca_s[d] == ca_r[d]] u_s[d] zc_r[d].
+    // The column's descriptor (ca, zc, z0: 13 words) sits in the registers of the lane that owns row r and
+    // is broadcast with v_readlane into SGPRs - no LDS round trip per column. Unused chain levels hold
+    // u = zc = 0, so a "match" of two empty levels adds nothing.
+    auto krow_lane = [](int k) { return k < 3 * MAXC - 1 ? CLANE0 + k : 0; };   // lane of contact row k
+    float Bm[NJMAX];
+#pragma unroll
+    for (int j = 1; j <= NJMAX; j++) {
+      float a0_ = 0.f;
+#pragma unroll
+      for (int d = 0; d < 6; d++) a0_ = __builtin_fmaf(r00[d], rl(z00[d], j), a0_);
+      {
+        const unsigned lowdiff = (unsigned)(__ffs((int)(ca0 ^ rl(ca0, j))) - 1);   // 0xffffffff: identical chains
 #pragma unroll
         for (int d = 0; d < MAXD; d++) {
-          const float m = (ca0[d] == bcast_i(ca0[d], j)) ? u0[d] : 0.f;
-          a0_ = __builtin_fmaf(m, bcast_f(zc0[d], j), a0_);
-        }
-        Bm[j - 1] = -inv0 * a0_;
-        W.jcol[j - 1][tid] = Bm[j - 1];
-      }
-      // -- contact columns -> registers; column k is row lane krow_lane(k), the chain is shared by a point's rows
-      float Bc[3 * MAXC];
-#pragma unroll
-      for (int c = 0; c < MAXC; c++) {
-#pragma unroll
-        for (int a = 0; a < 3; a++) Bc[3 * c + a] = 0.f;
-        if (c < ncE) {
-          float m0[MAXD];
-#pragma unroll
-          for (int d = 0; d < MAXD; d++) m0[d] = (ca0[d] == bcast_i(ca0[d], krow_lane(3 * c))) ? u0[d] : 0.f;
-#pragma unroll
-          for (int a = 0; a < 3; a++) {
-            const int k = 3 * c + a;
-            const int L = krow_lane(k);
-            float a0_ = 0.f;
-#pragma unroll
-            for (int d = 0; d < 6; d++) a0_ = __builtin_fmaf(r00[d], bcast_f(z00[d], L), a0_);
-#pragma unroll
-            for (int d = 0; d < MAXD; d++) a0_ = __builtin_fmaf(m0[d], bcast_f(zc0[d], L), a0_);
-            Bc[k] = -inv0 * a0_;
-          }
+          const float m = (lowdiff >= 5u * (d + 1)) ? u0[d] : 0.f;
+          a0_ = __builtin_fmaf(m, rl(zc0[d], j), a0_);
         }
       }
-      __syncthreads();
-      STAMP(10);
-      WPH(2);
-      // The launch lasts as long as its heaviest wave: let a wave with many rows win the issue arbitration
-      // against its lighter SIMD partner.
+      Bm[j - 1] = -inv0 * a0_;
+    }
+    if (lim_mask != 0u || DEBUG) {   // the dynamically indexed limit rows read their column from LDS
+#pragma unroll
+      for (int j = 1; j <= NJMAX; j++) W.u.jcol[j - 1][lt] = Bm[j - 1];
+    }
+    float Bc[3 * MAXC];
+    // Slots below s0 are never read. All 39 entries are first "defined" by an empty asm (no instruction): the
+    // live slots are then overwritten, the dead ones cost neither zeros to materialise nor a value carried
+    // around the substep loop.
+#pragma unroll
+    for (int k = 0; k < 3 * MAXC; k++) asm volatile("" : "=v"(Bc[k]));
+#pragma unroll
+    for (int s = 0; s < MAXC; s++) {
+      if (s >= s0) {
+        float m0[MAXD];
+        const unsigned lowdiff = (unsigned)(__ffs((int)(ca0 ^ rl(ca0, krow_lane(3 * s)))) - 1);
+#pragma unroll
+        for (int d = 0; d < MAXD; d++) m0[d] = (lowdiff >= 5u * (d + 1)) ? u0[d] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          const int k = 3 * s + a;
+          const int L = krow_lane(k);
+          float a0_ = 0.f;
+#pragma unroll
+          for (int d = 0; d < 6; d++) a0_ = __builtin_fmaf(r00[d], rl(z00[d], L), a0_);
+#pragma unroll
+          for (int d = 0; d < MAXD; d++) a0_ = __builtin_fmaf(m0[d], rl(zc0[d], L), a0_);
+          Bc[k] = -inv0 * a0_;
+        }
+      }
+    }
+    __syncthreads();
+    STAMP(6);
+    RELANE();
+
+    // ---- projected Gauss-Seidel in DELASSUS (residual) form. Each row s lives on ONE lane and keeps
+    //     y_s = rhs_s - (J_s dv) / diag_s            (its unclamped Gauss-Seidel increment)
+    // so a row visit is  nl = clamp(lam_r + y_r); d = nl - lam_r; lam_r = nl;  y_s += B_sr d  for all s
+    // (B_rr = -1) - the same iteration as Bullet's dv form (and the oracle's), but the row's impulse change
+    // reaches the other rows as ONE v_readlane (SGPR broadcast) + ONE fma per lane. y (not z = lam + y) is
+    // what is accumulated: it is small where lam is large, and the rounding of a row's own update stays in y.
+    // Row order (the oracle's): limit rows (ascending joint), motor rows, then per point normal, friction x, y.
+    float lam = 0.f, lim_lam = 0.f;
 #if TREX_PRIO_MODE == 1
-      {
-        const int groups = (ncE + 3) >> 2;
-        if (groups >= 4) __builtin_amdgcn_s_setprio(3);
-        else if (groups == 3) __builtin_amdgcn_s_setprio(2);
-        else if (groups == 2) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
-      }
+    set_priority(nc);
 #endif
-      float lim_lam = 0.f;
-#if TREX_STAMPS
-      unsigned long long acc_joint = 0;
-#endif
-      constexpr int GP = 4;
+    {
+#define TREX_ROW(LANE, BCOL, LO, HI)                                                                   \
+  {                                                                                                    \
+    const float nl_ = __builtin_amdgcn_fmed3f(lam + y, (LO), (HI));                                    \
+    const float d_ = nl_ - lam;                                                                        \
+    const float sd_ = rl(d_, (LANE));                                                                  \
+    if (vs == (LANE)) lam = nl_;                                                                       \
+    y = __builtin_fmaf((BCOL), sd_, y);                                                                \
+  }
+#define TREX_POINT(S)                                                                                  \
+  {                                                                                                    \
+    const float nl_ = fmaxf(lam + y, 0.f);                                                             \
+    const float d_ = nl_ - lam;                                                                        \
+    const float sd_ = rl(d_, krow_lane(3 * (S)));                                                      \
+    const float hi_ = mu * rl(nl_, krow_lane(3 * (S)));                                                \
+    if (vs == krow_lane(3 * (S))) lam = nl_;                                                           \
+    y = __builtin_fmaf(Bc[3 * (S)], sd_, y);                                                           \
+    TREX_ROW(krow_lane(3 * (S) + 1), Bc[3 * (S) + 1], -hi_, hi_)                                       \
+    TREX_ROW(krow_lane(3 * (S) + 2), Bc[3 * (S) + 2], -hi_, hi_)                                       \
+  }
+#pragma unroll 1
       for (int it = 0; it < iters; it++) {
-#if TREX_STAMPS
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        int vs = tid;   // opaque once per sweep: `vs == j` is one v_cmp where used, not a spilled mask
+        // the lane id, opaque once per sweep: `vs == j` is then one v_cmp where it is used, not a mask hoisted out
+        // of the loop and spilled. (A lane mask built on the scalar unit - s_lshl_b64 + v_cndmask - measured
+        // SLOWER than v_cmp + v_cndmask: 17.6 against 15.2 cycles per row and SIMD at 4 waves per SIMD,
+        // profiles/tools/row_bench.hip.)
+        int vs = lt;
         asm volatile("" : "+v"(vs));
-        // limit rows (ascending joint order, as the oracle): the row of joint j rides on motor lane j,
-        // whose y gives dv_j / diag = rhs - y
-        for (unsigned m = lmE; m != 0u; m &= m - 1u) {
+        // limit rows: the row of joint j rides on motor lane j, whose y gives dv_j / diag = rhs - y
+        for (unsigned m = lim_mask; m != 0u; m &= m - 1u) {
           const int j = __ffs(m) - 1;
           const float nl = fmaxf(lim_lam + (lr + ldir * y), 0.f);
           const float dl = (nl - lim_lam) * ldir;
           if (vs == j) lim_lam = nl;
-          const float sd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dl), j));
-          y += W.jcol[j - 1][tid] * sd;
+          const float sd = rl(dl, j);
+          y += W.u.jcol[j - 1][lt] * sd;
         }
 #pragma unroll
-        for (int j = 1; j <= NJMAX; j++) {   // joints beyond nb are null rows (y = 0, bounds 0)
-          const float nl = __builtin_amdgcn_fmed3f(lam + y, -mhi, mhi);
-          const float d = nl - lam;
-          const float sd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), j));
-          if (vs == j) lam = nl;
-          y += Bm[j - 1] * sd;
-        }
-#if TREX_STAMPS
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_sched_barrier(0);
-        acc_joint += ts1 - ts0;
-#endif
-#pragma unroll
-        for (int g = 0; g < (MAXC + GP - 1) / GP; g++) {
-          if (GP * g < ncE) {
-#pragma unroll
-            for (int cc = 0; cc < GP; cc++) {
-              const int c = GP * g + cc;
-              if (c >= MAXC) continue;
-              float hi = 0.f;
-#pragma unroll
-              for (int a = 0; a < 3; a++) {
-                const int k = 3 * c + a;
-                const int L = krow_lane(k);
-                float nl;
-                if (a == 0) nl = fmaxf(lam + y, 0.f);
-                else nl = __builtin_amdgcn_fmed3f(lam + y, -hi, hi);
-                const float d = nl - lam;
-                const float sd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), L));
-                if (a == 0) hi = muE * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nl), L));
-                if (vs == L) lam = nl;
-                y += Bc[k] * sd;
-              }
-              __builtin_amdgcn_sched_barrier(0);   // bound live ranges: one point per window
+        for (int j = 1; j <= NJMAX; j++) TREX_ROW(j, Bm[j - 1], -mhi, mhi)   // joints beyond nb are null rows (y = 0, bounds 0)
+        // the live point slots s0..12, in order. (A 13-way switch with fall-through is lowered to a tangle of
+        // flag registers and copies of y and lam; nested two-way tests cost 1 scalar branch for an airborne env
+        // and at most 13 for a full one.)
+        if (s0 <= 12) {
+          if (s0 <= 8) {
+            if (s0 <= 4) {
+              if (s0 <= 0) TREX_POINT(0)
+              if (s0 <= 1) TREX_POINT(1)
+              if (s0 <= 2) TREX_POINT(2)
+              if (s0 <= 3) TREX_POINT(3)
+              TREX_POINT(4)
             }
+            if (s0 <= 5) TREX_POINT(5)
+            if (s0 <= 6) TREX_POINT(6)
+            if (s0 <= 7) TREX_POINT(7)
+            TREX_POINT(8)
           }
+          if (s0 <= 9) TREX_POINT(9)
+          if (s0 <= 10) TREX_POINT(10)
+          if (s0 <= 11) TREX_POINT(11)
+          TREX_POINT(12)
         }
       }
-#if TREX_PRIO_MODE == 1
-      __builtin_amdgcn_s_setprio(0);
-#endif
-      STAMP(12);
-      WPH(3);
-#if TREX_STAMPS
-      if (DEBUG && args.debug && blockIdx.x == 0 && threadIdx.x == 0) {
-        args.debug[3000 + 16 * sub + 14] += (float)acc_joint;
-        args.debug[3000 + 16 * sub + 15] = (float)lmE;
-      }
-#endif
-      // -- results of env e. Joint lanes: dv_j / diag_j = -sum_r B_jr lam_r, summed afresh from the final
-      // impulses (rhs_j - y_j holds the same number, but as a difference of large terms when the motor is
-      // saturated). Base twist change = sum_r lam_r z0_r.
-      const bool mrow = tid >= 1 && tid <= NJMAX;
-      const float lt0 = lam + (mrow ? ldir * lim_lam : 0.f);   // motor + limit impulse of the joint
-      float dvj = 0.f;
-#pragma unroll
-      for (int j = 1; j <= NJMAX; j++) {
-        const float sl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lt0), j));
-        dvj -= Bm[j - 1] * sl;
-      }
-#pragma unroll
-      for (int g = 0; g < (MAXC + 3) / 4; g++) {
-        if (4 * g < ncE) {
-#pragma unroll
-          for (int k = 12 * g; k < 12 * g + 12 && k < 3 * MAXC; k++) {
-            const float sl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lam), krow_lane(k)));
-            dvj -= Bc[k] * sl;
-          }
-        }
-      }
-      float dvb[6];
-      {
-        const float *c0 = reinterpret_cast<const float *>(W.u.rows.col[row0]);
-#pragma unroll
-        for (int k = 0; k < 6; k++) dvb[k] = wsum(lt0 * c0[12 + k]);
-      }
-      const bool nrm0 = !mrow && (row0 - CROW0) % 3 == 0;
-      const float ni = wsum(nrm0 ? lam : 0.f);
-      {
-        // lanes 0..31 hold env e's joint results; every lane takes those of its own index within the team
-        float dlo = dvj * mdg;
-        {
-          const unsigned u = __float_as_uint(dlo);
-          const auto r2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-          dlo = __uint_as_float(r2[0]);
-        }
-        float mlo = lam;
-        {
-          const unsigned u = __float_as_uint(mlo);
-          const auto r2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-          mlo = __uint_as_float(r2[0]);
-        }
-        if (team == e) {
-          dv = is_joint ? dlo : 0.f;
-#pragma unroll
-          for (int k = 0; k < 6; k++)
-            if (is_base_dof_s && bdof_s == k) dv = dvb[k];
-          mot_lam = mlo;
-          nimp = ni;
-        }
-      }
-      if (DEBUG && args.debug && blockIdx.x == 0 && e == 0) {
-        float *D = args.debug;
-        // joint block of M^-1 recovered from the staged columns, contact impulses by row
-        if (team == 0) {
-#pragma unroll
-          for (int j = 1; j <= NJMAX; j++) D[160 + 32 * (j - 1) + lane] = is_joint ? -W.jcol[j - 1][lane] * mdiag : 0.f;
-        }
-#pragma unroll
-        for (int k = 0; k < 3 * MAXC; k++) {
-          const float l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lam), krow_lane(k)));
-          if (threadIdx.x == 0 && k / 3 < ncE) D[960 + (k / 3) * 16 + 11 + k % 3] = l;
-        }
-      }
-      __syncthreads();
+#undef TREX_ROW
+#undef TREX_POINT
     }
+#if TREX_PRIO_MODE == 1
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    STAMP(7);
+    RELANE();
+    REROW();
 
-    if (DEBUG && args.debug && blockIdx.x == 0 && team == 0) {
+    // ---- results. Joint lanes: dv_j / diag_j = -sum_r B_jr lam_r, summed afresh from the final impulses
+    // (rhs_j - y_j holds the same number, but as a difference of large terms when the motor is saturated).
+    // Base twist change = sum_r lam_r z0_r.
+    const float lt0 = lam + (mlane ? ldir * lim_lam : 0.f);   // motor + limit impulse of the joint
+    float dvj = 0.f;
+#pragma unroll
+    for (int j = 1; j <= NJMAX; j++) dvj -= Bm[j - 1] * rl(lt0, j);
+#pragma unroll
+    for (int s = 0; s < MAXC; s++) {
+      if (s >= s0) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) dvj -= Bc[3 * s + a] * rl(lam, krow_lane(3 * s + a));
+      }
+    }
+    float dvb[6];
+    {
+      const float *zs = reinterpret_cast<const float *>(W.body);
+#pragma unroll
+      for (int k = 0; k < 6; k++) dvb[k] = uni(wsum(lt0 * zs[64 * k + lt]));
+    }
+    const float nimp = uni(wsum((!mlane && cdir == 0) ? lam : 0.f));
+    const float mdg = W.st[ST_MDG][bl];
+    const float dv = mrow ? dvj * mdg : 0.f;
+
+    if (DEBUG && args.debug && blockIdx.x == 0) {
       float *D = args.debug;
-      D[lane] = qdd; D[64 + lane] = vg; D[96 + lane] = dv;
-      if (lane < 6) D[32 + lane] = a0[lane];
-      if (lane == 0) { D[128] = (float)nc; D[129] = (float)lim_mask; }
-      if (lane < nc) {
-        float *C = D + 960 + lane * 16;
-        C[0] = (float)cbody; C[1] = cx[0]; C[2] = cx[1]; C[3] = cx[2]; C[4] = cdist;
+      if (lt < TL) D[96 + lt] = dv;
+      if (lt == 0) {
+        for (int k = 0; k < 6; k++) D[96 + nb + k] = dvb[k];
+        D[128] = (float)nc; D[129] = (float)lim_mask;
+      }
+      // joint block of M^-1 recovered from the staged columns, contact points and their impulses
+      if (lt < TL) {
+#pragma unroll
+        for (int j = 1; j <= NJMAX; j++) D[160 + 32 * (j - 1) + lt] = mrow ? -W.u.jcol[j - 1][lt] * mdg : 0.f;
+      }
+      for (int c = 0; c < nc; c++) {
+        const float l0 = rl(lam, krow_lane(3 * (s0 + c))), l1 = rl(lam, krow_lane(3 * (s0 + c) + 1)), l2 = rl(lam, krow_lane(3 * (s0 + c) + 2));
+        if (lt == 0) {
+          float *C = D + 960 + c * 16;
+          C[0] = (float)__float_as_int(W.cpt[c][0]); C[1] = W.cpt[c][1]; C[2] = W.cpt[c][2]; C[3] = W.cpt[c][3]; C[4] = W.cpt[c][4];
+          C[11] = l0; C[12] = l1; C[13] = l2;
+        }
       }
     }
     __syncthreads();
 
-    // ---- commit velocities, integrate positions (only for a team that is really stepping)
-    if (live) {
-      vg += dv;
-      qd = is_joint ? vg : 0.f;
+    // ---- commit velocities, integrate positions
+    if (lt < TL) {
+      const float qd = is_joint ? W.st[ST_NQD][lt] + dv : 0.f;
+      W.st[ST_QD][lt] = qd;
+      W.st[ST_TAU][lt] = (mrow && motors_on) ? lam * inv_dt : 0.f;
+      W.st[ST_Q][lt] += qd * dt;
+    }
 #pragma unroll
-      for (int k = 0; k < 3; k++) { bw[k] = tshfl(vg, nb + k); bv[k] = tshfl(vg, nb + 3 + k); }
-      mtau = (is_joint && motors_on) ? mot_lam * inv_dt : 0.f;
-      q += qd * dt;
+    for (int k = 0; k < 3; k++) { bw[k] = uni(nw[k] + dvb[k]); bv[k] = uni(nv[k] + dvb[3 + k]); }
 #pragma unroll
-      for (int k = 0; k < 3; k++) pos[k] += bv[k] * dt;
+    for (int k = 0; k < 3; k++) pos[k] = uni(pos[k] + bv[k] * dt);
+    {
       const float wn = sqrtf(dot3(bw, bw)), th = wn * dt;
       float dq[4] = {0.f, 0.f, 0.f, 1.f};
       if (th > 1e-12f) {
@@ -1529,74 +1368,76 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
       o[2] = dq[3] * quat[2] + dq[0] * quat[1] - dq[1] * quat[0] + dq[2] * quat[3];
       const float qn = 1.0f / sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
 #pragma unroll
-      for (int k = 0; k < 4; k++) quat[k] = o[k] * qn;
-      stat_nc = nc;
-      stat_imp = nimp;
+      for (int k = 0; k < 4; k++) quat[k] = uni(o[k] * qn);
     }
-    STAMP(13);
-    WPH(4);
+    stat_nc = nc;
+    stat_imp = nimp;
+    __syncthreads();
+    STAMP(8);
+#undef RELANE
+#undef RETREE
+#undef REAXIS
+#undef REROW
   }
 
-  // ---- head position (needs FK at the new pose: getLinkState(computeForwardKinematics=1))
-  load_body_constants();
-  forward_kinematics();
+  // ---- epilogue: head position (needs FK at the new pose: getLinkState(computeForwardKinematics=1)), reward
+  const int lt = lane_id();
+  const int bl = lt & (TL - 1);
+  const bool is_body = lt < nb, is_joint = lt >= 1 && lt < nb;
   float head[3];
   {
+    const int parent = is_body ? M->parent[bl] : 0;
+    const int psrc = parent < 0 ? 0 : parent;
+    const int depth = is_body ? M->depth[bl] : -1;
+    float R[9], r[3], dpar[3], Sa[3];
+    forward_kinematics(lt, psrc, depth, R, r, dpar, Sa);
     const float hp[3] = {M->head_point[0], M->head_point[1], M->head_point[2]};
     float o[3];
     matvec3(R, hp, o);
+    const int hb = M->head_body;
 #pragma unroll
-    for (int k = 0; k < 3; k++) head[k] = tshfl(pos[k] + r[k] + o[k], M->head_body);
+    for (int k = 0; k < 3; k++) head[k] = rl(pos[k] + r[k] + o[k], hb);
   }
-  const float power = tsum(is_joint ? fabsf(qd * mtau) : 0.f);
+  float q = W.st[ST_Q][bl], qd = W.st[ST_QD][bl], mtau = W.st[ST_TAU][bl];
+  if (lt >= TL) { q = 0.f; qd = 0.f; mtau = 0.f; }
+  const float power = wsum(is_joint ? fabsf(qd * mtau) : 0.f);
   const float lift = args.w_distance * (2.5f - head[2]) * (2.5f - head[2]);
   const float drift = args.w_drift * (head[0] * head[0] + head[1] * head[1]);
   const float energy = args.w_energy * power;
 
-#if TREX_STAMPS
-  // per-wave duration and contact counts of its two envs (scripts/wave_balance.py; buffer >= 4 * 4096 floats)
-  if (DEBUG && args.debug && blockIdx.x < 4096) {
-    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    const int n1 = __shfl(stat_nc, 32);
-    if (threadIdx.x == 0) {
-      args.debug[4096 + blockIdx.x] = (float)(t_end - wave_t0);
-      args.debug[8192 + blockIdx.x] = (float)(stat_nc + 100 * n1);
-      args.debug[12288 + blockIdx.x] = (float)wave_cg;
-      args.debug[16384 + blockIdx.x] = (float)wave_cg1;
-      args.debug[20480 + blockIdx.x] = (float)wave_cg2;
-      args.debug[24576 + blockIdx.x] = (float)(dbg_bodies + 1000 * dbg_passes + 1000000 * dbg_trips);
-      for (int i = 0; i < 5; i++) args.debug[28672 + 4096 * i + blockIdx.x] = (float)wph[i];
-    }
-  }
-#endif
-  if (!env_ok) return;
   // ---- failure containment (no reference counterpart): an env whose state stopped being
   // finite is put back on the start pose with zero velocities and reports done = 1 once, with a finite
-  // reward of 0; it never poisons its wave partner (every cross-lane exchange stays inside the team).
-  bad |= !(fabsf(q) < 3.0e38f) || !(fabsf(qd) < 3.0e38f);
+  // reward of 0 (one env per wave: no other env can be affected).
+  bool badl = !(fabsf(q) < 3.0e38f) || !(fabsf(qd) < 3.0e38f);
 #pragma unroll
-  for (int k = 0; k < 3; k++) bad |= !(fabsf(pos[k]) < 3.0e38f) || !(fabsf(bv[k]) < 3.0e38f) || !(fabsf(bw[k]) < 3.0e38f);
+  for (int k = 0; k < 3; k++) badl |= !(fabsf(pos[k]) < 3.0e38f) || !(fabsf(bv[k]) < 3.0e38f) || !(fabsf(bw[k]) < 3.0e38f);
 #pragma unroll
-  for (int k = 0; k < 4; k++) bad |= !(fabsf(quat[k]) < 3.0e38f);
-  const bool env_bad = tballot(bad) != 0u;
+  for (int k = 0; k < 4; k++) badl |= !(fabsf(quat[k]) < 3.0e38f);
+  const bool env_bad = bad || (__ballot(badl) != 0ull);
   if (env_bad) {
 #pragma unroll
     for (int k = 0; k < 3; k++) { pos[k] = M->base_pos0[k]; bv[k] = 0.f; bw[k] = 0.f; }
 #pragma unroll
     for (int k = 0; k < 4; k++) quat[k] = M->base_quat0[k];
-    q = M->q_start[lane]; qd = 0.f; mtau = 0.f;
+    q = is_body ? M->q_start[bl] : 0.f; qd = 0.f; mtau = 0.f;
   }
   // ---- write back
   const bool store_state = RESET ? do_reset : true;
   if (store_state) {
-    float *b = args.arr.base + env * 16;
-    if (lane < 3) { b[lane] = pos[lane]; b[7 + lane] = bv[lane]; b[10 + lane] = bw[lane]; }
-    if (lane < 4) b[3 + lane] = quat[lane];
-    args.arr.q[env * TL + lane] = q;
-    args.arr.qd[env * TL + lane] = qd;
-    args.arr.tau[env * TL + lane] = mtau;
-    if (lane == 0) {
+    // base row: pos(3) quat(4) v(3) w(3); lane k < 13 stores word k (static selects: a dynamically indexed
+    // register array would be demoted to scratch memory)
+    float *b = args.arr.base + (size_t)env * 16;
+    const float row[13] = {pos[0], pos[1], pos[2], quat[0], quat[1], quat[2], quat[3], bv[0], bv[1], bv[2], bw[0], bw[1], bw[2]};
+    float word = row[0];
+#pragma unroll
+    for (int k = 1; k < 13; k++) word = (lt == k) ? row[k] : word;
+    if (lt < 13) b[lt] = word;
+    if (lt < TL) {
+      args.arr.q[(size_t)env * TL + lt] = q;
+      args.arr.qd[(size_t)env * TL + lt] = qd;
+      args.arr.tau[(size_t)env * TL + lt] = mtau;
+    }
+    if (lt == 0) {
       args.arr.motors_on[env] = motors_on ? 1 : 0;
       args.arr.contact_count[env] = stat_nc;
       args.arr.normal_impulse[env] = stat_imp;
@@ -1604,10 +1445,10 @@ __global__ __launch_bounds__(64, 2) void trex_step_kernel(KernelArgs args) {
   }
   if (args.obs && is_joint) {
     float *o = args.obs + (size_t)env * args.obs_stride;
-    const int obs_slot = M->obs_slot[lane];
+    const int obs_slot = M->obs_slot[bl];
     o[obs_slot] = q; o[nj + obs_slot] = qd; o[2 * nj + obs_slot] = mtau;
   }
-  if (lane == 0) {
+  if (lt == 0) {
     if (args.reward) args.reward[(size_t)env * args.scal_stride] = env_bad ? 0.f : -lift - drift - energy;
     if (args.done) args.done[env] = env_bad ? 1 : 0;  // should_terminate() is constant False, trex_env.py:183-184
     if (args.done_f) args.done_f[(size_t)env * args.scal_stride] = env_bad ? 1.f : 0.f;
@@ -1758,12 +1599,13 @@ __global__ void trex_copy_mass_scale_kernel(const float *src, float *dst, int n,
   dst[i] = l < nb ? src[e * nb + l] : 1.0f;
 }
 
-// Wave pairing. A wave solves its two envs one after the other, so its time is the SUM of their row counts
-// and the launch lasts as long as its heaviest wave: sort the envs by the contact count of their previous
-// step (counting sort, 14 bins) and give the k-th lightest env the k-th heaviest as wave partner. The
-// physics of an env does not depend on its partner (tests: permutation equivariance), so any order inside
-// a bin is fine. One workgroup; N / 1024 trips per thread.
-__global__ __launch_bounds__(1024) void trex_pair_kernel(const int32_t *contact_count, int32_t *perm, int n) {
+// Wave balance. All waves of the headline launch are resident at once (4096 envs = 4 waves on each of the 1024
+// SIMDs) and a SIMD is done when its slowest wave is: an env with many contact rows takes up to twice as long
+// as an airborne one. Workgroup k lands on SIMD k mod 1024 (up to a permutation: profiles/tools/census.hip),
+// so with the envs RANKED by the contact count of their previous step and workgroup k taking rank k, every
+// SIMD gets one env of each quarter of the ranking - never two heavy ones. (Counting sort, 16 bins, one
+// workgroup; the physics of an env does not depend on its slot: tests/ permutation equivariance.)
+__global__ __launch_bounds__(1024) void trex_balance_kernel(const int32_t *contact_count, int32_t *perm, int n) {
   __shared__ int hist[16], start[16], fill[16];
   const int t = threadIdx.x;
   if (t < 16) { hist[t] = 0; fill[t] = 0; }
@@ -1775,15 +1617,13 @@ __global__ __launch_bounds__(1024) void trex_pair_kernel(const int32_t *contact_
   __syncthreads();
   if (t == 0) {
     int acc = 0;
-    for (int b = 0; b < 16; b++) { start[b] = acc; acc += hist[b]; }
+    for (int b = 15; b >= 0; b--) { start[b] = acc; acc += hist[b]; }   // heaviest first
   }
   __syncthreads();
-  const int half = (n + 1) / 2;
   for (int i = t; i < n; i += 1024) {
     const int c = contact_count[i];
     const int b = c < 0 ? 0 : (c > 15 ? 15 : c);
-    const int pos = start[b] + atomicAdd(&fill[b], 1);   // rank by contact count
-    perm[pos < half ? 2 * pos : 2 * (n - 1 - pos) + 1] = i;
+    perm[start[b] + atomicAdd(&fill[b], 1)] = i;
   }
 }
 
@@ -1793,25 +1633,19 @@ extern "C" {
 hipError_t trex_launch_step(const TrexDeviceModel *model, TrexBatchArrays arr, int n, const float *actions,
                             float *obs, float *reward, uint8_t *done, float *penalties, float wd, float we,
                             float wk, float *debug, hipStream_t stream, float *done_f, int obs_stride, int scal_stride) {
-  // diagnostics launches keep env 0 and 1 in workgroup 0
-#if TREX_STAMPS
-  // diagnostic build: TREX_DEBUG_PAIR=1 keeps the pairing in debug launches (scripts/wave_balance.py)
-  const bool dbg_pair = getenv("TREX_DEBUG_PAIR") != nullptr;
-  const int32_t *perm = ((debug && !dbg_pair) || n < 4) ? nullptr : arr.pair_perm;
-#else
-  const int32_t *perm = (debug || n < 4) ? nullptr : arr.pair_perm;
-#endif
-  if (perm) hipLaunchKernelGGL(trex_pair_kernel, dim3(1), dim3(1024), 0, stream, arr.contact_count, arr.pair_perm, n);
+  // diagnostics launches keep env 0 in workgroup 0
+  const int32_t *perm = (debug || n < 2048 || getenv("TREX_NO_BALANCE")) ? nullptr : arr.pair_perm;
+  if (perm) hipLaunchKernelGGL(trex_balance_kernel, dim3(1), dim3(1024), 0, stream, arr.contact_count, arr.pair_perm, n);
   KernelArgs a{model, arr, n, actions, obs, reward, done, done_f, obs_stride, scal_stride, penalties, nullptr, perm, wd, we, wk, debug};
-  if (debug) hipLaunchKernelGGL((trex_step_kernel<false, true>), dim3((n + 1) / 2), dim3(64), 0, stream, a);
-  else hipLaunchKernelGGL((trex_step_kernel<false, false>), dim3((n + 1) / 2), dim3(64), 0, stream, a);
+  if (debug) hipLaunchKernelGGL((trex_step_kernel<false, true>), dim3(n), dim3(64), 0, stream, a);
+  else hipLaunchKernelGGL((trex_step_kernel<false, false>), dim3(n), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
 
 hipError_t trex_launch_reset(const TrexDeviceModel *model, TrexBatchArrays arr, int n, const uint8_t *mask,
                              float *obs, float wd, float we, float wk, float *debug, hipStream_t stream, int obs_stride) {
   KernelArgs a{model, arr, n, nullptr, obs, nullptr, nullptr, nullptr, obs_stride, 1, nullptr, mask, nullptr, wd, we, wk, debug};
-  hipLaunchKernelGGL((trex_step_kernel<true, false>), dim3((n + 1) / 2), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL((trex_step_kernel<true, false>), dim3(n), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
 
@@ -1847,5 +1681,6 @@ hipError_t trex_launch_copy_mass_scale(const float *src, float *dst, int n, int 
 }
 
 int trex_step_lds_bytes(void) { return (int)sizeof(WaveLds); }
+int trex_step_envs_per_workgroup(void) { return 1; }
 
 }  // extern "C"
