@@ -16,7 +16,7 @@ __global__ __launch_bounds__(64) void k(float *out, long long *cyc, int sweeps, 
   float B[NR];
 #pragma unroll
   for (int j = 0; j < NR; j++) B[j] = (tid == j + 1) ? -1.f : 1e-3f * (float)((tid * 7 + j * 13) % 11 - 5);
-  float y = 0.01f * (tid + 1), lam = 0.f;
+  float y = 0.01f * (tid + 1), lam = 0.f, blo = -hi, bhi = hi;
   const long long t0 = __builtin_amdgcn_s_memtime();
 #pragma unroll 1
   for (int it = 0; it < sweeps; it++) {
@@ -53,6 +53,17 @@ __global__ __launch_bounds__(64) void k(float *out, long long *cyc, int sweeps, 
         const float sd = rl(y, L);
         lam = __builtin_amdgcn_inverse_ballot_w64(one << L) ? lam + y : lam;
         y = __builtin_fmaf(B[j], sd, y);
+      } else if (VARIANT == 6) {   // short chain: d = med3(y, lo - lam, hi - lam) with the shifted bounds kept per lane
+        const float d = __builtin_amdgcn_fmed3f(y, blo, bhi);
+        const float sd = rl(d, L);
+        y = __builtin_fmaf(B[j], sd, y);
+        const float dm = (vs == L) ? d : 0.f;
+        lam += dm; blo -= dm; bhi -= dm;
+      } else if (VARIANT == 7) {   // short chain, bounds formed from lam before the visit
+        const float d = __builtin_amdgcn_fmed3f(y, -hi - lam, hi - lam);
+        const float sd = rl(d, L);
+        y = __builtin_fmaf(B[j], sd, y);
+        lam += (vs == L) ? d : 0.f;
       } else if (VARIANT == 5) {   // unclamped, lam not tracked (lower bound: readlane + fma)
         const float sd = rl(y, L);
         y = __builtin_fmaf(B[j], sd, y);
@@ -60,7 +71,7 @@ __global__ __launch_bounds__(64) void k(float *out, long long *cyc, int sweeps, 
     }
   }
   const long long t1 = __builtin_amdgcn_s_memtime();
-  out[blockIdx.x * 64 + tid] = y + lam;
+  out[blockIdx.x * 64 + tid] = y + lam + blo + bhi;
   if (tid == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
@@ -92,5 +103,7 @@ int main() {
   run<3>("3 unclamped: exec-masked v_add", out, cyc, sweeps);
   run<4>("4 unclamped: v_add + v_cndmask", out, cyc, sweeps);
   run<5>("5 unclamped, lam untracked (bound)", out, cyc, sweeps);
+  run<6>("6 short chain, shifted bounds kept", out, cyc, sweeps);
+  run<7>("7 short chain, bounds from lam", out, cyc, sweeps);
   return 0;
 }

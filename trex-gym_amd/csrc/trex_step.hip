@@ -61,7 +61,7 @@
     __builtin_amdgcn_sched_barrier(0);                                                    \
     const unsigned long long _t = __builtin_amdgcn_s_memtime();                           \
     __builtin_amdgcn_s_waitcnt(0xC07F);                                                   \
-    if (DEBUG && args.debug && threadIdx.x == 0) args.debug[4096 + (i) * args.n_envs + blockIdx.x] += (float)(_t - stamp_last); \
+    if (args.debug && threadIdx.x == 0) args.debug[4096 + (i) * args.n_envs + blockIdx.x] += (float)(_t - stamp_last); \
     stamp_last = _t;                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                    \
   } while (0)
@@ -269,13 +269,14 @@ constexpr int CLANE0 = NJMAX + 1;        // contact row k lives on lane CLANE0 +
 // 16 lanes reading 16 different records hit 16 different bank quartets):
 //   q0 = joint axis (world) xyz | 1/D      q1 = origin r (rel. base origin) xyz | updated joint rate
 //   q2 = (U/D)[0..3]                       q3 = (U/D)[4..5] | parent + 256 * depth (int) | -
-//   q4 = offset from the parent's origin xyz | -
+//   q4 = offset from the parent's origin xyz | children, 8 bits each (int)
 constexpr int BREC = 5;                  // float4s per record
 struct WaveLds {
   float4 body[32 * BREC];     // 2560 B; after the row walks: z0 stash [6][64] for the base twist change
   union {
-    float aba[32][28];        // tip-to-base staging, Ia (21) + pa (6) per body                3584 B
-    float jcol[NJMAX][64];    // [j-1][row lane]: B entries of motor column j (limit rows)     6400 B
+    float aba[32][28];        // tip-to-base pass: articulated inertia (21) + bias force (6) per body      3584 B
+    float4 desc[64][4];       // B build: column descriptor of the row on lane L: chain | zc[6] | z0[6]     4096 B
+    float jcol[NJMAX][64];    // sweeps: [j-1][row lane] = B entries of motor column j (limit rows)        6400 B
   } u;
   float cpt[MAXC][8];         // contact points: body, x, y, z (rel. base origin), distance     416 B
   float st[6][TL];            // per body lane, parked across the phases: q, qd, motor torque, target, updated rate, 1/M^-1_jj  768 B
@@ -468,7 +469,16 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
         rec[0] = make_float4(Sa0[0], Sa0[1], Sa0[2], 0.f);
         rec[1] = make_float4(r[0], r[1], r[2], 0.f);
         rec[3] = make_float4(0.f, 0.f, __int_as_float(psrc + 256 * (depth < 0 ? 255 : depth)), 0.f);
-        rec[4] = make_float4(dpar0[0], dpar0[1], dpar0[2], 0.f);
+        // children, 8 bits each (255 = none): the tip-to-base pass reads them here, not from the model (4 dependent
+        // L2 round trips per level)
+        const TrexDeviceModel *Mi = Mo();
+        unsigned ch4 = 0u;
+#pragma unroll
+        for (int k = 0; k < MAXCH; k++) {
+          const int c = is_body ? Mi->child[k][bl] : -1;
+          ch4 |= (unsigned)(c < 0 ? 255 : c) << (8 * k);
+        }
+        rec[4] = make_float4(dpar0[0], dpar0[1], dpar0[2], __uint_as_float(ch4));
       }
     }
     // (axis, parent offset, parent and depth are re-read from the record by the phases that sweep the tree)
@@ -927,11 +937,11 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
           float *o = W.u.aba[bl];
 #pragma unroll
           for (int k = 0; k < 27; k++) acc[k] = o[k];
-          const TrexDeviceModel *Mj = Mo();
+          const unsigned ch4 = __float_as_uint(reinterpret_cast<const float *>(&W.body[BREC * bl + 4])[3]);
 #pragma unroll 1
           for (int kc = 0; kc < MAXCH; kc++) {   // children in fixed order (one child's 27 words in flight at a time)
-            const int ch = Mj->child[kc][bl];
-            if (ch >= 0) {
+            const int ch = (int)((ch4 >> (8 * kc)) & 255u);
+            if (ch != 255) {
               const float *c = W.u.aba[ch];
 #pragma unroll
               for (int k = 0; k < 27; k++) acc[k] += c[k];
@@ -1148,40 +1158,57 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
       }
     }
     const unsigned lim_mask = (unsigned)__ballot(ldir != 0.f);
-    __syncthreads();   // the body records are dead: the z0 stash may overwrite them
+    __syncthreads();   // the body records are dead: the z0 stash may overwrite them; so are the inertia slots
     {
       float *zs = reinterpret_cast<float *>(W.body);
 #pragma unroll
       for (int k = 0; k < 6; k++) zs[64 * k + lt] = z00[k];
+      // column side of this lane's row, for every other lane to read (one address per column: LDS broadcast)
+      float4 *dc = W.u.desc[lt];
+      dc[0] = make_float4(__uint_as_float(ca0), zc0[0], zc0[1], zc0[2]);
+      dc[1] = make_float4(zc0[3], zc0[4], zc0[5], z00[0]);
+      dc[2] = make_float4(z00[1], z00[2], z00[3], z00[4]);
+      dc[3] = make_float4(z00[5], 0.f, 0.f, 0.f);
     }
+    __syncthreads();
     STAMP(5);
     RELANE();
 
     // ---- B entries of this lane's row against every column: B_sr = -(J_s M^-1 J_r^T) / diag_s with
     //     J_s M^-1 J_r^T = r0_s . z0_r + sum_d [ca_s[d] == ca_r[d]] u_s[d] zc_r[d].
-    // The column's descriptor (ca, zc, z0: 13 words) sits in the registers of the lane that owns row r and
-    // is broadcast with v_readlane into SGPRs - no LDS round trip per column. Unused chain levels hold
-    // u = zc = 0, so a "match" of two empty levels adds nothing.
+    // The column's descriptor (chain, zc, z0: 13 words) is read from LDS at ONE address by all lanes (broadcast,
+    // no VALU) - the v_readlane form of it cost 13 VALU per column. Unused chain levels hold u = zc = 0, so a
+    // "match" of two empty levels adds nothing.
     auto krow_lane = [](int k) { return k < 3 * MAXC - 1 ? CLANE0 + k : 0; };   // lane of contact row k
+    auto column = [&](int L, const float *m, float4 d0, float4 d1, float4 d2, float4 d3) {
+      float a0_ = r00[0] * d1.w;
+      a0_ = __builtin_fmaf(r00[1], d2.x, a0_); a0_ = __builtin_fmaf(r00[2], d2.y, a0_);
+      a0_ = __builtin_fmaf(r00[3], d2.z, a0_); a0_ = __builtin_fmaf(r00[4], d2.w, a0_);
+      a0_ = __builtin_fmaf(r00[5], d3.x, a0_);
+      a0_ = __builtin_fmaf(m[0], d0.y, a0_); a0_ = __builtin_fmaf(m[1], d0.z, a0_); a0_ = __builtin_fmaf(m[2], d0.w, a0_);
+      a0_ = __builtin_fmaf(m[3], d1.x, a0_); a0_ = __builtin_fmaf(m[4], d1.y, a0_); a0_ = __builtin_fmaf(m[5], d1.z, a0_);
+      return -inv0 * a0_;
+    };
+    auto chain_mask = [&](float4 d0, float *m) {   // u of this row on the levels it shares with the column's chain
+      const unsigned lowdiff = (unsigned)(__ffs((int)(ca0 ^ __float_as_uint(d0.x))) - 1);   // 0xffffffff: identical chains
+#pragma unroll
+      for (int d = 0; d < MAXD; d++) m[d] = (lowdiff >= 5u * (d + 1)) ? u0[d] : 0.f;
+    };
+    // (one column's 4 reads in flight while the previous column is evaluated - pinned by sched_barrier: left to
+    // itself the scheduler hoists the reads of ALL columns, 400 registers)
     float Bm[NJMAX];
+    {
+      float4 n0 = W.u.desc[1][0], n1 = W.u.desc[1][1], n2 = W.u.desc[1][2], n3 = W.u.desc[1][3];
 #pragma unroll
-    for (int j = 1; j <= NJMAX; j++) {
-      float a0_ = 0.f;
-#pragma unroll
-      for (int d = 0; d < 6; d++) a0_ = __builtin_fmaf(r00[d], rl(z00[d], j), a0_);
-      {
-        const unsigned lowdiff = (unsigned)(__ffs((int)(ca0 ^ rl(ca0, j))) - 1);   // 0xffffffff: identical chains
-#pragma unroll
-        for (int d = 0; d < MAXD; d++) {
-          const float m = (lowdiff >= 5u * (d + 1)) ? u0[d] : 0.f;
-          a0_ = __builtin_fmaf(m, rl(zc0[d], j), a0_);
-        }
+      for (int j = 1; j <= NJMAX; j++) {
+        const float4 d0 = n0, d1 = n1, d2 = n2, d3 = n3;
+        if (j < NJMAX) { n0 = W.u.desc[j + 1][0]; n1 = W.u.desc[j + 1][1]; n2 = W.u.desc[j + 1][2]; n3 = W.u.desc[j + 1][3]; }
+        float m[MAXD];
+        chain_mask(d0, m);
+        Bm[j - 1] = column(j, m, d0, d1, d2, d3);
+        asm volatile("" : "+v"(Bm[j - 1]));   // evaluated HERE (not sunk to its first use in the sweeps)
+        __builtin_amdgcn_sched_barrier(0);
       }
-      Bm[j - 1] = -inv0 * a0_;
-    }
-    if (lim_mask != 0u || DEBUG) {   // the dynamically indexed limit rows read their column from LDS
-#pragma unroll
-      for (int j = 1; j <= NJMAX; j++) W.u.jcol[j - 1][lt] = Bm[j - 1];
     }
     float Bc[3 * MAXC];
     // Slots below s0 are never read. All 39 entries are first "defined" by an empty asm (no instruction): the
@@ -1192,22 +1219,22 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
 #pragma unroll
     for (int s = 0; s < MAXC; s++) {
       if (s >= s0) {
-        float m0[MAXD];
-        const unsigned lowdiff = (unsigned)(__ffs((int)(ca0 ^ rl(ca0, krow_lane(3 * s)))) - 1);
-#pragma unroll
-        for (int d = 0; d < MAXD; d++) m0[d] = (lowdiff >= 5u * (d + 1)) ? u0[d] : 0.f;
+        float m[MAXD];
 #pragma unroll
         for (int a = 0; a < 3; a++) {
-          const int k = 3 * s + a;
-          const int L = krow_lane(k);
-          float a0_ = 0.f;
-#pragma unroll
-          for (int d = 0; d < 6; d++) a0_ = __builtin_fmaf(r00[d], rl(z00[d], L), a0_);
-#pragma unroll
-          for (int d = 0; d < MAXD; d++) a0_ = __builtin_fmaf(m0[d], rl(zc0[d], L), a0_);
-          Bc[k] = -inv0 * a0_;
+          const float4 *dc = W.u.desc[krow_lane(3 * s + a)];
+          const float4 d0 = dc[0], d1 = dc[1], d2 = dc[2], d3 = dc[3];
+          if (a == 0) chain_mask(d0, m);   // the three rows of a point share its chain
+          Bc[3 * s + a] = column(0, m, d0, d1, d2, d3);
+          asm volatile("" : "+v"(Bc[3 * s + a]));
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
+    }
+    __syncthreads();   // every lane is done with the descriptors: the limit rows' columns may take their place
+    if (lim_mask != 0u || DEBUG) {   // the dynamically indexed limit rows read their column from LDS
+#pragma unroll
+      for (int j = 1; j <= NJMAX; j++) W.u.jcol[j - 1][lt] = Bm[j - 1];
     }
     __syncthreads();
     STAMP(6);
@@ -1233,16 +1260,23 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
     if (vs == (LANE)) lam = nl_;                                                                       \
     y = __builtin_fmaf((BCOL), sd_, y);                                                                \
   }
+// A point with no normal impulse before this visit (lam_n = 0) and none after it (lam_n + y_n <= 0) changes
+// nothing: its normal row gives d = 0, its friction rows are clamped to 0 and hold 0 already (they were visited
+// after the normal row lost its impulse). Under random actions 9 in 10 candidate points are like that - inside the
+// 2 cm margin, not pressing - so the three rows are skipped behind one wave-uniform test (bitwise the same result:
+// the skipped updates would add B * 0).
 #define TREX_POINT(S)                                                                                  \
   {                                                                                                    \
     const float nl_ = fmaxf(lam + y, 0.f);                                                             \
-    const float d_ = nl_ - lam;                                                                        \
-    const float sd_ = rl(d_, krow_lane(3 * (S)));                                                      \
-    const float hi_ = mu * rl(nl_, krow_lane(3 * (S)));                                                \
-    if (vs == krow_lane(3 * (S))) lam = nl_;                                                           \
-    y = __builtin_fmaf(Bc[3 * (S)], sd_, y);                                                           \
-    TREX_ROW(krow_lane(3 * (S) + 1), Bc[3 * (S) + 1], -hi_, hi_)                                       \
-    TREX_ROW(krow_lane(3 * (S) + 2), Bc[3 * (S) + 2], -hi_, hi_)                                       \
+    if (rl(__float_as_uint(nl_) | __float_as_uint(lam), krow_lane(3 * (S))) != 0u) {                   \
+      const float d_ = nl_ - lam;                                                                      \
+      const float sd_ = rl(d_, krow_lane(3 * (S)));                                                    \
+      const float hi_ = mu * rl(nl_, krow_lane(3 * (S)));                                              \
+      if (vs == krow_lane(3 * (S))) lam = nl_;                                                         \
+      y = __builtin_fmaf(Bc[3 * (S)], sd_, y);                                                         \
+      TREX_ROW(krow_lane(3 * (S) + 1), Bc[3 * (S) + 1], -hi_, hi_)                                     \
+      TREX_ROW(krow_lane(3 * (S) + 2), Bc[3 * (S) + 2], -hi_, hi_)                                     \
+    }                                                                                                  \
   }
 #pragma unroll 1
       for (int it = 0; it < iters; it++) {
@@ -1261,8 +1295,12 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
           const float sd = rl(dl, j);
           y += W.u.jcol[j - 1][lt] * sd;
         }
+        // motor rows (joints beyond nb are null rows: y = 0, bounds 0). (A speculative unclamped block - d_j = y_j
+        // by v_readlane / v_writelane / v_fmac, 4 issue slots per row instead of 8, committed only if no bound was
+        // crossed - does not pay: under random actions the heavy links' motors DO saturate at 3e5 N m, the
+        // block then runs twice; 3.62 M against 4.17 M env-steps/s.)
 #pragma unroll
-        for (int j = 1; j <= NJMAX; j++) TREX_ROW(j, Bm[j - 1], -mhi, mhi)   // joints beyond nb are null rows (y = 0, bounds 0)
+        for (int j = 1; j <= NJMAX; j++) TREX_ROW(j, Bm[j - 1], -mhi, mhi)
         // the live point slots s0..12, in order. (A 13-way switch with fall-through is lowered to a tangle of
         // flag registers and copies of y and lam; nested two-way tests cost 1 scalar branch for an airborne env
         // and at most 13 for a full one.)
@@ -1637,8 +1675,12 @@ hipError_t trex_launch_step(const TrexDeviceModel *model, TrexBatchArrays arr, i
   const int32_t *perm = (debug || n < 2048 || getenv("TREX_NO_BALANCE")) ? nullptr : arr.pair_perm;
   if (perm) hipLaunchKernelGGL(trex_balance_kernel, dim3(1), dim3(1024), 0, stream, arr.contact_count, arr.pair_perm, n);
   KernelArgs a{model, arr, n, actions, obs, reward, done, done_f, obs_stride, scal_stride, penalties, nullptr, perm, wd, we, wk, debug};
+#if TREX_STAMPS   // diagnostic build: the PRODUCT instantiation, stamped (the dump of <false, true> would change its code)
+  hipLaunchKernelGGL((trex_step_kernel<false, false>), dim3(n), dim3(64), 0, stream, a);
+#else
   if (debug) hipLaunchKernelGGL((trex_step_kernel<false, true>), dim3(n), dim3(64), 0, stream, a);
   else hipLaunchKernelGGL((trex_step_kernel<false, false>), dim3(n), dim3(64), 0, stream, a);
+#endif
   return hipGetLastError();
 }
 
