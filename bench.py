@@ -229,9 +229,8 @@ def main():
         blocking_ms = tm_.item()
         t_base += 5 + nb
         gather_mode[0] = "pipelined"
+    hist0 = contact_hist()   # (before the warm-up: nothing but the mandatory fence sits between warm-up and timing)
     run(args.warmup, t_base)
-    fence()
-    hist0 = contact_hist()
     fence()
     t0 = time.perf_counter()
     run(args.steps, t_base + args.warmup, timed=True)

@@ -209,54 +209,48 @@ __device__ __forceinline__ void sym6_rank1_sub(Sym6 &m, const float *U, float s)
     for (int c = 0; c < 3; c++) m.B[3 * r + c] -= U[r] * U[3 + c] * s;
 }
 
-// inverse of an SPD 6x6 (Cholesky), result as 21 unique entries of the symmetric inverse, row-major
-// upper triangle: inv[tri(r,c)], r<=c
-__device__ __forceinline__ constexpr int tri(int r, int c) { return r * 6 - r * (r - 1) / 2 + (c - r); }
-__device__ __forceinline__ void spd6_inverse(const float *a, float *inv21) {   // a: full 6x6, row-major
-  float l[36];
+// SPD 6x6 systems (the base's articulated inertia): Cholesky factor L kept as its 15 strictly-lower entries
+// (row-major, l[i (i - 1) / 2 + j], j < i) and the 6 RECIPROCAL diagonal entries; a solve is a forward and a back
+// substitution, 30 fma + 12 mul. No explicit inverse, no division, no IEEE sqrt expansion: the reciprocal roots
+// come from v_rsq_f32 with one Newton step.
+struct Chol6 { float l[15], il[6]; };
+__device__ __forceinline__ constexpr int lidx(int i, int j) { return i * (i - 1) / 2 + j; }
+__device__ __forceinline__ float rsqrt_nr(float s) {
+  const float r0 = __builtin_amdgcn_rsqf(s);
+  const float e = __builtin_fmaf(-s * r0, r0, 1.0f);   // 1 - s r0^2
+  return __builtin_fmaf(0.5f * r0, e, r0);
+}
+__device__ __forceinline__ void chol6_factor(const float *a, Chol6 &c) {   // a: full 6x6, row-major (lower part read)
 #pragma unroll
-  for (int i = 0; i < 36; i++) l[i] = 0.f;
+  for (int j = 0; j < 6; j++) {
+    float s = a[6 * j + j];
 #pragma unroll
-  for (int i = 0; i < 6; i++)
+    for (int k = 0; k < j; k++) s -= c.l[lidx(j, k)] * c.l[lidx(j, k)];
+    c.il[j] = rsqrt_nr(s);
 #pragma unroll
-    for (int j = 0; j <= i; j++) {
-      float s = a[6 * i + j];
+    for (int i = j + 1; i < 6; i++) {
+      float t = a[6 * i + j];
 #pragma unroll
-      for (int k = 0; k < j; k++) s -= l[6 * i + k] * l[6 * j + k];
-      if (i == j) l[6 * i + j] = sqrtf(s);
-      else l[6 * i + j] = s / l[6 * j + j];
-    }
-  // Linv (lower triangular), then inv = Linv^T Linv
-  float li[36];
-#pragma unroll
-  for (int i = 0; i < 36; i++) li[i] = 0.f;
-#pragma unroll
-  for (int c = 0; c < 6; c++) {
-#pragma unroll
-    for (int i = c; i < 6; i++) {
-      float s = (i == c) ? 1.f : 0.f;
-#pragma unroll
-      for (int k = c; k < i; k++) s -= l[6 * i + k] * li[6 * k + c];
-      li[6 * i + c] = s / l[6 * i + i];
+      for (int k = 0; k < j; k++) t -= c.l[lidx(i, k)] * c.l[lidx(j, k)];
+      c.l[lidx(i, j)] = t * c.il[j];
     }
   }
-#pragma unroll
-  for (int r = 0; r < 6; r++)
-#pragma unroll
-    for (int c = r; c < 6; c++) {
-      float s = 0.f;
-#pragma unroll
-      for (int k = c; k < 6; k++) s += li[6 * k + r] * li[6 * k + c];
-      inv21[tri(r, c)] = s;
-    }
 }
-__device__ __forceinline__ void inv21_mul(const float *inv21, const float *v, float *o) {
+__device__ __forceinline__ void chol6_solve(const Chol6 &c, const float *r, float *z) {
+  float w[6];
 #pragma unroll
-  for (int r = 0; r < 6; r++) {
-    float s = 0.f;
+  for (int i = 0; i < 6; i++) {
+    float t = r[i];
 #pragma unroll
-    for (int c = 0; c < 6; c++) s += inv21[r <= c ? tri(r, c) : tri(c, r)] * v[c];
-    o[r] = s;
+    for (int k = 0; k < i; k++) t -= c.l[lidx(i, k)] * w[k];
+    w[i] = t * c.il[i];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    float t = w[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; k++) t -= c.l[lidx(k, i)] * z[k];
+    z[i] = t * c.il[i];
   }
 }
 
@@ -860,95 +854,102 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
     RETREE();
     REAXIS();
 
-    // ---- ABA pass 2 (tip to base) on LDS-resident inertias: slot b of W.u.aba holds body b's articulated
-    // inertia (21) and bias force (6) about its own origin. At level d the lanes AT depth d take their slot -
-    // complete by then -, form U, 1/D, u (which go to the body record: pass 3 and the row walks read them there),
-    // remove the joint's freedom, shift to the parent's origin and put the result back; the lanes at depth d-1
-    // then add their children's slots to their own. Nothing of this is carried in registers between levels.
+    // ---- ABA pass 2 (tip to base) on LDS-resident inertias: slot b of W.u.aba holds body b's rigid-body inertia
+    // (21) and bias force (6) about its own origin. Level by level, the lanes AT depth d take their slot, add
+    // what their children left in theirs (already shifted to this body's origin; fixed order), form U, 1/D, u
+    // (which go to the body record: pass 3 and the row walks read them there), remove the joint's freedom,
+    // shift to the parent's origin and put the result back for the parent. One LDS round trip and one barrier
+    // per level; nothing of this is carried in registers between levels. Level 0 is the base: it only sums.
     {
       const TrexDeviceModel *Mi = Mo();
       const float tau_j = -Mi->damp[bl] * W.st[ST_QD][bl];  // explicit joint damping torque
-      for (int d = maxdepth; d >= 1; d--) {
+      for (int d = maxdepth; d >= 0; d--) {
         if (depth == d) {
           float *o = W.u.aba[bl];
-          Sym6 IA;
-          float pA[6];
-#pragma unroll
-          for (int k = 0; k < 6; k++) { IA.A[k] = o[k]; IA.C[k] = o[15 + k]; pA[k] = o[21 + k]; }
-#pragma unroll
-          for (int k = 0; k < 9; k++) IA.B[k] = o[6 + k];
-          float U[6];   // U = IA S, S = [Sa; 0]
-          sym3_mul(IA.A, Sa, U);
-          U[3] = IA.B[0] * Sa[0] + IA.B[3] * Sa[1] + IA.B[6] * Sa[2];
-          U[4] = IA.B[1] * Sa[0] + IA.B[4] * Sa[1] + IA.B[7] * Sa[2];
-          U[5] = IA.B[2] * Sa[0] + IA.B[5] * Sa[1] + IA.B[8] * Sa[2];
-          const float invD = 1.0f / dot3(Sa, U);
-          const float u = tau_j - dot3(Sa, pA);
-          {
-            float4 *rec = &W.body[BREC * bl];
-            rec[0] = make_float4(Sa[0], Sa[1], Sa[2], invD);
-            rec[2] = make_float4(U[0] * invD, U[1] * invD, U[2] * invD, U[3] * invD);
-            rec[3] = make_float4(U[4] * invD, U[5] * invD, __int_as_float(psrc + 256 * depth), u * invD);
-          }
-          {   // pa = pA + Ia c + U u / D with Ia c = IA c - U (U.c) / D
-            float Ic[6];
-            sym6_mul(IA, cv, Ic);
-            const float coef = (u - dot6(U, cv)) * invD;
-#pragma unroll
-            for (int k = 0; k < 6; k++) pA[k] += Ic[k] + U[k] * coef;
-          }
-          sym6_rank1_sub(IA, U, invD);
-          // shift both to the parent's origin (this origin = parent origin + d, d = dpar):
-          //   n' = n + d x f,  B' = B + [d]x C,  A' = A + X^T + X', X = [d]x B^T, X' = [d]x B'^T
-          {
-            float t[3];
-            cross3(dpar, pA + 3, t);
-#pragma unroll
-            for (int k = 0; k < 3; k++) pA[k] += t[k];
-            const int sidx[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
-#pragma unroll
-            for (int i = 0; i < 3; i++) {   // A_ij += X_ji = (d x row i of B)_j
-              cross3(dpar, IA.B + 3 * i, t);
-#pragma unroll
-              for (int j = i; j < 3; j++) IA.A[sidx[i][j]] += t[j];
-            }
-#pragma unroll
-            for (int j = 0; j < 3; j++) {   // column j of [d]x C = d x (column j of C)
-              const float cj[3] = {IA.C[sidx[0][j]], IA.C[sidx[1][j]], IA.C[sidx[2][j]]};
-              cross3(dpar, cj, t);
-#pragma unroll
-              for (int i = 0; i < 3; i++) IA.B[3 * i + j] += t[i];
-            }
-#pragma unroll
-            for (int j = 0; j < 3; j++) {   // A_ij += X'_ij = (d x row j of B')_i
-              cross3(dpar, IA.B + 3 * j, t);
-#pragma unroll
-              for (int i = 0; i <= j; i++) IA.A[sidx[i][j]] += t[i];
-            }
-          }
-#pragma unroll
-          for (int k = 0; k < 6; k++) { o[k] = IA.A[k]; o[15 + k] = IA.C[k]; o[21 + k] = pA[k]; }
-#pragma unroll
-          for (int k = 0; k < 9; k++) o[6 + k] = IA.B[k];
-        }
-        __syncthreads();
-        if (depth == d - 1) {
-          float acc[27];
-          float *o = W.u.aba[bl];
-#pragma unroll
-          for (int k = 0; k < 27; k++) acc[k] = o[k];
           const unsigned ch4 = __float_as_uint(reinterpret_cast<const float *>(&W.body[BREC * bl + 4])[3]);
-#pragma unroll 1
-          for (int kc = 0; kc < MAXCH; kc++) {   // children in fixed order (one child's 27 words in flight at a time)
-            const int ch = (int)((ch4 >> (8 * kc)) & 255u);
-            if (ch != 255) {
-              const float *c = W.u.aba[ch];
+          float acc[27];
+          {
+            // own slot and first child's in flight together (most bodies have exactly one child)
+            const int c0 = (int)(ch4 & 255u);
+            const float *c = W.u.aba[c0 == 255 ? bl : c0];
+            const float w0 = c0 == 255 ? 0.f : 1.f;
 #pragma unroll
-              for (int k = 0; k < 27; k++) acc[k] += c[k];
-            }
+            for (int k = 0; k < 27; k++) acc[k] = __builtin_fmaf(w0, c[k], o[k]);
           }
+#pragma unroll 1
+          for (int kc = 1; kc < MAXCH; kc++) {   // further children, fixed order (packed without gaps)
+            const int ch = (int)((ch4 >> (8 * kc)) & 255u);
+            if (ch == 255) break;
+            const float *c = W.u.aba[ch];
 #pragma unroll
-          for (int k = 0; k < 27; k++) o[k] = acc[k];
+            for (int k = 0; k < 27; k++) acc[k] += c[k];
+          }
+          if (d == 0) {
+#pragma unroll
+            for (int k = 0; k < 27; k++) o[k] = acc[k];
+          } else {
+            Sym6 IA;
+            float pA[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) { IA.A[k] = acc[k]; IA.C[k] = acc[15 + k]; pA[k] = acc[21 + k]; }
+#pragma unroll
+            for (int k = 0; k < 9; k++) IA.B[k] = acc[6 + k];
+            float U[6];   // U = IA S, S = [Sa; 0]
+            sym3_mul(IA.A, Sa, U);
+            U[3] = IA.B[0] * Sa[0] + IA.B[3] * Sa[1] + IA.B[6] * Sa[2];
+            U[4] = IA.B[1] * Sa[0] + IA.B[4] * Sa[1] + IA.B[7] * Sa[2];
+            U[5] = IA.B[2] * Sa[0] + IA.B[5] * Sa[1] + IA.B[8] * Sa[2];
+            const float D = dot3(Sa, U);
+            const float rD = __builtin_amdgcn_rcpf(D);
+            const float invD = rD * __builtin_fmaf(-D, rD, 2.0f);   // v_rcp_f32 + one Newton step (no IEEE division expansion)
+            const float u = tau_j - dot3(Sa, pA);
+            {
+              float4 *rec = &W.body[BREC * bl];
+              rec[0] = make_float4(Sa[0], Sa[1], Sa[2], invD);
+              rec[2] = make_float4(U[0] * invD, U[1] * invD, U[2] * invD, U[3] * invD);
+              rec[3] = make_float4(U[4] * invD, U[5] * invD, __int_as_float(psrc + 256 * depth), u * invD);
+            }
+            {   // pa = pA + Ia c + U u / D with Ia c = IA c - U (U.c) / D
+              float Ic[6];
+              sym6_mul(IA, cv, Ic);
+              const float coef = (u - dot6(U, cv)) * invD;
+#pragma unroll
+              for (int k = 0; k < 6; k++) pA[k] += Ic[k] + U[k] * coef;
+            }
+            sym6_rank1_sub(IA, U, invD);
+            // shift both to the parent's origin (this origin = parent origin + d, d = dpar):
+            //   n' = n + d x f,  B' = B + [d]x C,  A' = A + X^T + X', X = [d]x B^T, X' = [d]x B'^T
+            {
+              float t[3];
+              cross3(dpar, pA + 3, t);
+#pragma unroll
+              for (int k = 0; k < 3; k++) pA[k] += t[k];
+              const int sidx[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+#pragma unroll
+              for (int i = 0; i < 3; i++) {   // A_ij += X_ji = (d x row i of B)_j
+                cross3(dpar, IA.B + 3 * i, t);
+#pragma unroll
+                for (int j = i; j < 3; j++) IA.A[sidx[i][j]] += t[j];
+              }
+#pragma unroll
+              for (int j = 0; j < 3; j++) {   // column j of [d]x C = d x (column j of C)
+                const float cj[3] = {IA.C[sidx[0][j]], IA.C[sidx[1][j]], IA.C[sidx[2][j]]};
+                cross3(dpar, cj, t);
+#pragma unroll
+                for (int i = 0; i < 3; i++) IA.B[3 * i + j] += t[i];
+              }
+#pragma unroll
+              for (int j = 0; j < 3; j++) {   // A_ij += X'_ij = (d x row j of B')_i
+                cross3(dpar, IA.B + 3 * j, t);
+#pragma unroll
+                for (int i = 0; i <= j; i++) IA.A[sidx[i][j]] += t[i];
+              }
+            }
+#pragma unroll
+            for (int k = 0; k < 6; k++) { o[k] = IA.A[k]; o[15 + k] = IA.C[k]; o[21 + k] = pA[k]; }
+#pragma unroll
+            for (int k = 0; k < 9; k++) o[6 + k] = IA.B[k];
+          }
         }
         __syncthreads();
       }
@@ -964,8 +965,9 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
     RETREE();
     REAXIS();
 
-    // ---- floating base: a0 = -(IA_0)^-1 pA_0; the inverse is wave-uniform (SGPRs)
-    float I0inv[21], a0[6];
+    // ---- floating base: a0 = -(IA_0)^-1 pA_0; the Cholesky factor of IA_0 is wave-uniform (SGPRs)
+    Chol6 I0c;
+    float a0[6];
     {
       const float *o = W.u.aba[0];   // every lane reads the same words: LDS broadcast
       Sym6 I0;
@@ -976,12 +978,15 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
       float p0[6];
 #pragma unroll
       for (int k = 0; k < 6; k++) p0[k] = -o[21 + k];
-      float full[36], inv_l[21];
+      float full[36];
       sym6_full(I0, full);
-      spd6_inverse(full, inv_l);
+      Chol6 c;
+      chol6_factor(full, c);
 #pragma unroll
-      for (int k = 0; k < 21; k++) I0inv[k] = uni(inv_l[k]);
-      inv21_mul(I0inv, p0, a0);
+      for (int k = 0; k < 15; k++) I0c.l[k] = uni(c.l[k]);
+#pragma unroll
+      for (int k = 0; k < 6; k++) I0c.il[k] = uni(c.il[k]);
+      chol6_solve(I0c, p0, a0);
 #pragma unroll
       for (int k = 0; k < 6; k++) a0[k] = uni(a0[k]);
     }
@@ -1056,7 +1061,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
     REROW();
     // Every row walks its chain to the base ONCE: the generalised force J^T is pushed through the ABA
     // factorisation (u_a = -a_a . n, p += (U/D)_a u_a), which yields the row's column of A (u), the same
-    // divided by D (zc), the base wrench r0 and z0 = I0^-1 r0 - and, for a contact row, the plain Jacobian
+    // divided by D (zc), the base wrench r0 and z0 = I0^-1 r0 (two triangular solves) - and, for a contact row, the plain Jacobian
     // entries for J.v on the way. A motor row is the unit force on its own joint: u = 1 at its own level.
     // ca0: the chain, 5 bits per level (depth-1 ancestor in the low bits, 0 = none): two rows share the joints
     // of their common prefix, so "same joint at level d" is "the lowest differing bit lies above field d"
@@ -1128,7 +1133,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
       }
 #pragma unroll
       for (int k = 0; k < 6; k++) r00[k] = live ? -p[k] : 0.f;
-      inv21_mul(I0inv, r00, z00);
+      chol6_solve(I0c, r00, z00);
       diag += dot6(r00, z00);
       inv0 = live ? 1.0f / diag : 0.f;
       const TrexDeviceModel *Mi = Mo();
