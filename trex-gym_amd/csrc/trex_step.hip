@@ -1265,24 +1265,27 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
     if (vs == (LANE)) lam = nl_;                                                                       \
     y = __builtin_fmaf((BCOL), sd_, y);                                                                \
   }
-// A point with no normal impulse before this visit (lam_n = 0) and none after it (lam_n + y_n <= 0) changes
+// A point with no normal impulse before its visit (lam_n = 0) and none after it (lam_n + y_n <= 0) changes
 // nothing: its normal row gives d = 0, its friction rows are clamped to 0 and hold 0 already (they were visited
 // after the normal row lost its impulse). Under random actions 9 in 10 candidate points are like that - inside the
-// 2 cm margin, not pressing - so the three rows are skipped behind one wave-uniform test (bitwise the same result:
-// the skipped updates would add B * 0).
+// 2 cm margin, not pressing. ONE vector test over all normal-row lanes (`alive_points`) therefore precedes the point
+// blocks: a dead point costs a scalar bit test, and the test is repeated after every point that was processed
+// (it changed y). Bitwise the same result as visiting every row: the skipped updates would add B * 0.
 #define TREX_POINT(S)                                                                                  \
-  {                                                                                                    \
+  if (alive & (1ull << krow_lane(3 * (S)))) {                                                          \
     const float nl_ = fmaxf(lam + y, 0.f);                                                             \
-    if (rl(__float_as_uint(nl_) | __float_as_uint(lam), krow_lane(3 * (S))) != 0u) {                   \
-      const float d_ = nl_ - lam;                                                                      \
-      const float sd_ = rl(d_, krow_lane(3 * (S)));                                                    \
-      const float hi_ = mu * rl(nl_, krow_lane(3 * (S)));                                              \
-      if (vs == krow_lane(3 * (S))) lam = nl_;                                                         \
-      y = __builtin_fmaf(Bc[3 * (S)], sd_, y);                                                         \
-      TREX_ROW(krow_lane(3 * (S) + 1), Bc[3 * (S) + 1], -hi_, hi_)                                     \
-      TREX_ROW(krow_lane(3 * (S) + 2), Bc[3 * (S) + 2], -hi_, hi_)                                     \
-    }                                                                                                  \
+    const float d_ = nl_ - lam;                                                                        \
+    const float sd_ = rl(d_, krow_lane(3 * (S)));                                                      \
+    const float hi_ = mu * rl(nl_, krow_lane(3 * (S)));                                                \
+    if (vs == krow_lane(3 * (S))) lam = nl_;                                                           \
+    y = __builtin_fmaf(Bc[3 * (S)], sd_, y);                                                           \
+    TREX_ROW(krow_lane(3 * (S) + 1), Bc[3 * (S) + 1], -hi_, hi_)                                       \
+    TREX_ROW(krow_lane(3 * (S) + 2), Bc[3 * (S) + 2], -hi_, hi_)                                       \
+    alive = alive_points();                                                                            \
   }
+      // lanes that hold the normal row of a live point slot
+      const unsigned long long nrm_mask = __ballot(lt >= CLANE0 && (lt - CLANE0) % 3 == 0 && (lt - CLANE0) / 3 >= s0);
+      auto alive_points = [&]() { return nrm_mask & __ballot(lam != 0.f || lam + y > 0.f); };
 #pragma unroll 1
       for (int it = 0; it < iters; it++) {
         // the lane id, opaque once per sweep: `vs == j` is then one v_cmp where it is used, not a mask hoisted out
@@ -1300,33 +1303,205 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
           const float sd = rl(dl, j);
           y += W.u.jcol[j - 1][lt] * sd;
         }
-        // motor rows (joints beyond nb are null rows: y = 0, bounds 0). (A speculative unclamped block - d_j = y_j
-        // by v_readlane / v_writelane / v_fmac, 4 issue slots per row instead of 8, committed only if no bound was
-        // crossed - does not pay: under random actions the heavy links' motors DO saturate at 3e5 N m, the
-        // block then runs twice; 3.62 M against 4.17 M env-steps/s.)
-#pragma unroll
-        for (int j = 1; j <= NJMAX; j++) TREX_ROW(j, Bm[j - 1], -mhi, mhi)
-        // the live point slots s0..12, in order. (A 13-way switch with fall-through is lowered to a tangle of
-        // flag registers and copies of y and lam; nested two-way tests cost 1 scalar branch for an airborne env
-        // and at most 13 for a full one.)
-        if (s0 <= 12) {
-          if (s0 <= 8) {
-            if (s0 <= 4) {
-              if (s0 <= 0) TREX_POINT(0)
-              if (s0 <= 1) TREX_POINT(1)
-              if (s0 <= 2) TREX_POINT(2)
-              if (s0 <= 3) TREX_POINT(3)
-              TREX_POINT(4)
-            }
-            if (s0 <= 5) TREX_POINT(5)
-            if (s0 <= 6) TREX_POINT(6)
-            if (s0 <= 7) TREX_POINT(7)
-            TREX_POINT(8)
-          }
-          if (s0 <= 9) TREX_POINT(9)
-          if (s0 <= 10) TREX_POINT(10)
-          if (s0 <= 11) TREX_POINT(11)
-          TREX_POINT(12)
+        // motor rows (joints beyond nb are null rows: y = 0, bounds 0), hand-placed: 7 issue slots per row instead of
+        // the compiler's 8. The impulse change d_j, which sits in an SGPR for the broadcast anyway, is captured into
+        // lane j of `dvec` with v_writelane (1 VALU instead of v_cmp + v_cndmask) and the 25 impulses are committed
+        // after the block, lam += dvec. The v_writelane of row j-1 is the wait state between v_sub and the v_readlane
+        // of its result; s_nop 1 covers the two wait states between v_readlane and the v_fmac that reads the SGPR.
+        // (A speculative UNCLAMPED block - d_j = y_j, 4 slots per row, committed only if no bound was crossed - does
+        // not pay: under random actions 7 percent of the motor rows sit at 3e5 N m and the block then runs twice.)
+        {
+          static_assert(NJMAX == 25, "the blocks below are written out for 25 motor rows");
+          int dvec = 0, sa_, sb_;
+          float t_, d_;
+          asm volatile("v_add_f32_e32 %2, %6, %0\n\t"
+                       "v_med3_f32 %2, %2, -%7, %7\n\t"
+                       "v_sub_f32_e32 %3, %2, %6\n\t"
+                       "s_nop 0\n\t"
+                       "v_readlane_b32 %4, %3, 1\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_e32 %0, %4, %8\n\t"
+                       "v_add_f32_e32 %2, %6, %0\n\t"
+                       "v_med3_f32 %2, %2, -%7, %7\n\t"
+                       "v_sub_f32_e32 %3, %2, %6\n\t"
+                       "v_writelane_b32 %1, %4, 1\n\t"
+                       "v_readlane_b32 %5, %3, 2\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_e32 %0, %5, %9\n\t"
+                       "v_add_f32_e32 %2, %6, %0\n\t"
+                       "v_med3_f32 %2, %2, -%7, %7\n\t"
+                       "v_sub_f32_e32 %3, %2, %6\n\t"
+                       "v_writelane_b32 %1, %5, 2\n\t"
+                       "v_readlane_b32 %4, %3, 3\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_e32 %0, %4, %10\n\t"
+                       "v_add_f32_e32 %2, %6, %0\n\t"
+                       "v_med3_f32 %2, %2, -%7, %7\n\t"
+                       "v_sub_f32_e32 %3, %2, %6\n\t"
+                       "v_writelane_b32 %1, %4, 3\n\t"
+                       "v_readlane_b32 %5, %3, 4\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_e32 %0, %5, %11\n\t"
+                       "v_add_f32_e32 %2, %6, %0\n\t"
+                       "v_med3_f32 %2, %2, -%7, %7\n\t"
+                       "v_sub_f32_e32 %3, %2, %6\n\t"
+                       "v_writelane_b32 %1, %5, 4\n\t"
+                       "v_readlane_b32 %4, %3, 5\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_e32 %0, %4, %12\n\t"
+                       "v_add_f32_e32 %2, %6, %0\n\t"
+                       "v_med3_f32 %2, %2, -%7, %7\n\t"
+                       "v_sub_f32_e32 %3, %2, %6\n\t"
+                       "v_writelane_b32 %1, %4, 5\n\t"
+                       "v_readlane_b32 %5, %3, 6\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_e32 %0, %5, %13\n\t"
+                       "v_add_f32_e32 %2, %6, %0\n\t"
+                       "v_med3_f32 %2, %2, -%7, %7\n\t"
+                       "v_sub_f32_e32 %3, %2, %6\n\t"
+                       "v_writelane_b32 %1, %5, 6\n\t"
+                       "v_readlane_b32 %4, %3, 7\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_e32 %0, %4, %14\n\t"
+                       "v_add_f32_e32 %2, %6, %0\n\t"
+                       "v_med3_f32 %2, %2, -%7, %7\n\t"
+                       "v_sub_f32_e32 %3, %2, %6\n\t"
+                       "v_writelane_b32 %1, %4, 7\n\t"
+                       "v_readlane_b32 %5, %3, 8\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_e32 %0, %5, %15\n\t"
+                       "v_add_f32_e32 %2, %6, %0\n\t"
+                       "v_med3_f32 %2, %2, -%7, %7\n\t"
+                       "v_sub_f32_e32 %3, %2, %6\n\t"
+                       "v_writelane_b32 %1, %5, 8\n\t"
+                       "v_readlane_b32 %4, %3, 9\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_e32 %0, %4, %16\n\t"
+                       "v_add_f32_e32 %2, %6, %0\n\t"
+                       "v_med3_f32 %2, %2, -%7, %7\n\t"
+                       "v_sub_f32_e32 %3, %2, %6\n\t"
+                       "v_writelane_b32 %1, %4, 9\n\t"
+                       "v_readlane_b32 %5, %3, 10\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_e32 %0, %5, %17\n\t"
+                       "v_add_f32_e32 %2, %6, %0\n\t"
+                       "v_med3_f32 %2, %2, -%7, %7\n\t"
+                       "v_sub_f32_e32 %3, %2, %6\n\t"
+                       "v_writelane_b32 %1, %5, 10\n\t"
+                       "v_readlane_b32 %4, %3, 11\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_e32 %0, %4, %18\n\t"
+                       "v_add_f32_e32 %2, %6, %0\n\t"
+                       "v_med3_f32 %2, %2, -%7, %7\n\t"
+                       "v_sub_f32_e32 %3, %2, %6\n\t"
+                       "v_writelane_b32 %1, %4, 11\n\t"
+                       "v_readlane_b32 %5, %3, 12\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_e32 %0, %5, %19\n\t"
+                       "v_add_f32_e32 %2, %6, %0\n\t"
+                       "v_med3_f32 %2, %2, -%7, %7\n\t"
+                       "v_sub_f32_e32 %3, %2, %6\n\t"
+                       "v_writelane_b32 %1, %5, 12\n\t"
+                       "v_readlane_b32 %4, %3, 13\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_e32 %0, %4, %20\n\t"
+                       "v_writelane_b32 %1, %4, 13\n\t"
+                       : "+v"(y), "+v"(dvec), "=&v"(t_), "=&v"(d_), "=&s"(sa_), "=&s"(sb_)
+                       : "v"(lam), "v"(mhi), "v"(Bm[0]), "v"(Bm[1]), "v"(Bm[2]), "v"(Bm[3]), "v"(Bm[4]), "v"(Bm[5]), "v"(Bm[6]), "v"(Bm[7]), "v"(Bm[8]), "v"(Bm[9]), "v"(Bm[10]), "v"(Bm[11]), "v"(Bm[12]));
+          asm volatile("v_add_f32_e32 %2, %6, %0\n\t"
+                       "v_med3_f32 %2, %2, -%7, %7\n\t"
+                       "v_sub_f32_e32 %3, %2, %6\n\t"
+                       "s_nop 0\n\t"
+                       "v_readlane_b32 %5, %3, 14\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_e32 %0, %5, %8\n\t"
+                       "v_add_f32_e32 %2, %6, %0\n\t"
+                       "v_med3_f32 %2, %2, -%7, %7\n\t"
+                       "v_sub_f32_e32 %3, %2, %6\n\t"
+                       "v_writelane_b32 %1, %5, 14\n\t"
+                       "v_readlane_b32 %4, %3, 15\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_e32 %0, %4, %9\n\t"
+                       "v_add_f32_e32 %2, %6, %0\n\t"
+                       "v_med3_f32 %2, %2, -%7, %7\n\t"
+                       "v_sub_f32_e32 %3, %2, %6\n\t"
+                       "v_writelane_b32 %1, %4, 15\n\t"
+                       "v_readlane_b32 %5, %3, 16\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_e32 %0, %5, %10\n\t"
+                       "v_add_f32_e32 %2, %6, %0\n\t"
+                       "v_med3_f32 %2, %2, -%7, %7\n\t"
+                       "v_sub_f32_e32 %3, %2, %6\n\t"
+                       "v_writelane_b32 %1, %5, 16\n\t"
+                       "v_readlane_b32 %4, %3, 17\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_e32 %0, %4, %11\n\t"
+                       "v_add_f32_e32 %2, %6, %0\n\t"
+                       "v_med3_f32 %2, %2, -%7, %7\n\t"
+                       "v_sub_f32_e32 %3, %2, %6\n\t"
+                       "v_writelane_b32 %1, %4, 17\n\t"
+                       "v_readlane_b32 %5, %3, 18\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_e32 %0, %5, %12\n\t"
+                       "v_add_f32_e32 %2, %6, %0\n\t"
+                       "v_med3_f32 %2, %2, -%7, %7\n\t"
+                       "v_sub_f32_e32 %3, %2, %6\n\t"
+                       "v_writelane_b32 %1, %5, 18\n\t"
+                       "v_readlane_b32 %4, %3, 19\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_e32 %0, %4, %13\n\t"
+                       "v_add_f32_e32 %2, %6, %0\n\t"
+                       "v_med3_f32 %2, %2, -%7, %7\n\t"
+                       "v_sub_f32_e32 %3, %2, %6\n\t"
+                       "v_writelane_b32 %1, %4, 19\n\t"
+                       "v_readlane_b32 %5, %3, 20\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_e32 %0, %5, %14\n\t"
+                       "v_add_f32_e32 %2, %6, %0\n\t"
+                       "v_med3_f32 %2, %2, -%7, %7\n\t"
+                       "v_sub_f32_e32 %3, %2, %6\n\t"
+                       "v_writelane_b32 %1, %5, 20\n\t"
+                       "v_readlane_b32 %4, %3, 21\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_e32 %0, %4, %15\n\t"
+                       "v_add_f32_e32 %2, %6, %0\n\t"
+                       "v_med3_f32 %2, %2, -%7, %7\n\t"
+                       "v_sub_f32_e32 %3, %2, %6\n\t"
+                       "v_writelane_b32 %1, %4, 21\n\t"
+                       "v_readlane_b32 %5, %3, 22\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_e32 %0, %5, %16\n\t"
+                       "v_add_f32_e32 %2, %6, %0\n\t"
+                       "v_med3_f32 %2, %2, -%7, %7\n\t"
+                       "v_sub_f32_e32 %3, %2, %6\n\t"
+                       "v_writelane_b32 %1, %5, 22\n\t"
+                       "v_readlane_b32 %4, %3, 23\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_e32 %0, %4, %17\n\t"
+                       "v_add_f32_e32 %2, %6, %0\n\t"
+                       "v_med3_f32 %2, %2, -%7, %7\n\t"
+                       "v_sub_f32_e32 %3, %2, %6\n\t"
+                       "v_writelane_b32 %1, %4, 23\n\t"
+                       "v_readlane_b32 %5, %3, 24\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_e32 %0, %5, %18\n\t"
+                       "v_add_f32_e32 %2, %6, %0\n\t"
+                       "v_med3_f32 %2, %2, -%7, %7\n\t"
+                       "v_sub_f32_e32 %3, %2, %6\n\t"
+                       "v_writelane_b32 %1, %5, 24\n\t"
+                       "v_readlane_b32 %4, %3, 25\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_e32 %0, %4, %19\n\t"
+                       "v_writelane_b32 %1, %4, 25\n\t"
+                       : "+v"(y), "+v"(dvec), "=&v"(t_), "=&v"(d_), "=&s"(sa_), "=&s"(sb_)
+                       : "v"(lam), "v"(mhi), "v"(Bm[13]), "v"(Bm[14]), "v"(Bm[15]), "v"(Bm[16]), "v"(Bm[17]), "v"(Bm[18]), "v"(Bm[19]), "v"(Bm[20]), "v"(Bm[21]), "v"(Bm[22]), "v"(Bm[23]), "v"(Bm[24]));
+          lam += __int_as_float(dvec);
+        }
+        // the live point slots, in order (dead slots have no bit in `alive`)
+        unsigned long long alive = alive_points();
+        if (alive != 0ull) {
+          TREX_POINT(0) TREX_POINT(1) TREX_POINT(2) TREX_POINT(3) TREX_POINT(4) TREX_POINT(5) TREX_POINT(6)
+          TREX_POINT(7) TREX_POINT(8) TREX_POINT(9) TREX_POINT(10) TREX_POINT(11) TREX_POINT(12)
         }
       }
 #undef TREX_ROW
