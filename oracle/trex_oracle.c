@@ -303,14 +303,20 @@ typedef struct { int body; int vert; real x[3]; real dist; } Contact;
 /* Hull vertices against the half-space z <= floor_z.  A vertex is a candidate when its distance
  * to the plane is below contact_margin.  Per body at most K points are kept, K =
  * clamp(max_contacts / (#bodies with candidates), 1, 4): deepest; farthest from it in the plane;
- * farthest from that line; farthest on the other side of the line.  Ties -> lowest vertex index. */
+ * farthest from that line; farthest on the other side of the line.  Ties -> lowest vertex index.
+ * With MORE touching bodies than max_contacts the budget goes to the bodies whose deepest vertex is
+ * deepest (ties -> lower body index), one point each, emitted in body order - not to the lowest body
+ * indices, which would leave a whole leg without contact rows (no counterpart in Bullet, which has no
+ * such budget). */
 static int generate_contacts(const Model *m, const State *s, const Work *k, Contact *out) {
   const real margin = m->prm[P_CONTACT_MARGIN], fz = m->prm[P_FLOOR_Z];
   int maxc = (int)m->prm[P_MAX_CONTACTS];
   if (maxc > MAXC) maxc = MAXC;
   int active[NBMAX], n_active = 0;
+  real deepest[NBMAX];
   for (int b = 0; b < m->nb; b++) {
     active[b] = 0;
+    deepest[b] = 0;
     int n = m->hull_start[b + 1] - m->hull_start[b];
     if (!n) continue;
     real c[3];
@@ -319,14 +325,26 @@ static int generate_contacts(const Model *m, const State *s, const Work *k, Cont
     if (cz - m->sphere_r[b] - fz >= margin) continue;
     const real *Rz = k->R[b] + 6;
     real z0 = s->pos[2] + k->r[b][2] - fz;
-    for (int v = m->hull_start[b]; v < m->hull_start[b + 1]; v++)
-      if (z0 + dot3(Rz, m->hull + 3 * v) - m->hull_r[v] < margin) { active[b] = 1; break; }
+    for (int v = m->hull_start[b]; v < m->hull_start[b + 1]; v++) {
+      real d = z0 + dot3(Rz, m->hull + 3 * v) - m->hull_r[v];
+      if (d < margin && (!active[b] || d < deepest[b])) { active[b] = 1; deepest[b] = d; }
+    }
     n_active += active[b];
   }
   if (!n_active) return 0;
   int K = maxc / n_active;
   if (K > 4) K = 4;
   if (K < 1) K = 1;
+  if (n_active > maxc) {
+    for (int b = 0; b < m->nb; b++) {
+      if (!active[b]) continue;
+      int rank = 0;
+      for (int b2 = 0; b2 < m->nb; b2++)
+        if (active[b2] && (deepest[b2] < deepest[b] || (deepest[b2] == deepest[b] && b2 < b))) rank++;
+      if (rank >= maxc) active[b] = 2; /* over budget */
+    }
+    for (int b = 0; b < m->nb; b++) if (active[b] == 2) active[b] = 0;
+  }
   int nc = 0;
   for (int b = 0; b < m->nb && nc < maxc; b++) {
     if (!active[b]) continue;

@@ -4,7 +4,8 @@ committed golden rollouts, and - at BASELINE's full 4096 envs - through size-ind
 
 Stated tolerances (f32 kernel vs f64 oracle; PGS amplifies rounding in contact):
   one env-step from an identical state: |dq| <= 1e-4 rad, |dqd| <= 5e-3 * max(1, |qd|_inf),
-  motor torque <= 5e-3 * max|tau| (+1 N m), reward <= 2e-3 relative (+1e-3)
+  motor torque <= 5e-3 * max|tau| over the unsaturated joints (+1 N m), saturated joints saturated alike,
+  reward <= 2e-3 relative (+1e-3, + a tenth of what the qd / tau tolerances allow in the energy term)
   contact-free trajectories (8..25 steps): |dq| <= 1e-4, |dqd| <= 5e-4 * max(1, |qd|_inf)
 Measured over 252 states, 152 of them in contact (scripts/parity_stats.py): max |dq| 3.7e-5,
 |dqd| 7.7e-4, torque 9.0e-4, reward 3.8e-4 (medians 1e-7 .. 3e-6); airborne states 3e-7 .. 1e-5.
@@ -33,16 +34,28 @@ def make_vec(n, **kw):
     return TrexVecEnv(n, urdf_path=ASSET_URDF, device=DEV, **kw)
 
 
-def assert_step_close(g_obs, o_obs, g_rew=None, o_rew=None, what="", q_atol=1e-4):
+def assert_step_close(g_obs, o_obs, g_rew=None, o_rew=None, what="", q_atol=1e-4, loosen=1.0):
     J = 25
     assert np.isfinite(g_obs).all(), what
     np.testing.assert_allclose(g_obs[:J], o_obs[:J], atol=q_atol, rtol=0, err_msg=what + " q")
-    np.testing.assert_allclose(g_obs[J:2 * J], o_obs[J:2 * J], atol=5e-3 * max(1.0, np.abs(o_obs[J:2 * J]).max()),
+    np.testing.assert_allclose(g_obs[J:2 * J], o_obs[J:2 * J], atol=loosen * 5e-3 * max(1.0, np.abs(o_obs[J:2 * J]).max()),
                                rtol=0, err_msg=what + " qd")
-    np.testing.assert_allclose(g_obs[2 * J:], o_obs[2 * J:], atol=5e-3 * np.abs(o_obs[2 * J:]).max() + 1.0, rtol=0,
-                               err_msg=what + " tau")
+    # motor torque: a joint saturated in the oracle (3e5 N m, trex_robot.py:260) must be saturated with the same sign;
+    # the others are compared on the scale of the largest UNsaturated torque (a saturated neighbour must not hide
+    # an error of hundreds of N m)
+    gt, ot = g_obs[2 * J:], o_obs[2 * J:]
+    sat = np.abs(ot) >= 0.999 * 3.0e5
+    assert np.all(np.abs(gt[sat]) >= 0.999 * 3.0e5) and np.all(np.sign(gt[sat]) == np.sign(ot[sat])), what + " saturated tau"
+    if (~sat).any():
+        tscale = np.abs(ot[~sat]).max()
+        np.testing.assert_allclose(gt[~sat], ot[~sat], atol=5e-3 * tscale + 1.0, rtol=0, err_msg=what + " tau")
     if g_rew is not None:
-        assert abs(g_rew - o_rew) <= 2e-3 * abs(o_rew) + 1e-3, (what, g_rew, o_rew)
+        # reward = -lift - drift - w_e sum|qd tau| (trex_env.py:186-192): 2e-3 relative on the whole, plus what the
+        # stated qd / tau tolerances allow in the energy term (w_e = 0.005, the default of every test here)
+        qd_tol = 5e-3 * max(1.0, np.abs(o_obs[J:2 * J]).max())
+        tau_tol = np.where(sat, 1e-3 * 3.0e5, 5e-3 * (np.abs(ot[~sat]).max() if (~sat).any() else 0.0) + 1.0)
+        energy_tol = 0.005 * np.sum(np.abs(o_obs[J:2 * J]) * tau_tol + np.abs(ot) * qd_tol)
+        assert abs(g_rew - o_rew) <= 2e-3 * abs(o_rew) + 1e-3 + 0.1 * energy_tol, (what, g_rew, o_rew)
 
 
 def test_native_library_is_the_one_loaded(capi):
@@ -161,10 +174,11 @@ def test_long_rollout_statistics(oracle64, model):
 def test_joint_limit_rows(oracle64, oracle32, model):
     """Every joint 0.05 rad past its stop with saturated motors pushing further: 25 limit rows fight 25
     motor rows. 60 PGS sweeps are far from converged on the neck chain (947 kg cranium behind a 12 kg
-    atlas, tests/test_oracle_physics.py::test_joint_limit_rows), so f32 rounding is amplified there:
-    the f32 build of the ORACLE differs from its f64 build by 2% on those two joints, and two f32
-    evaluations with different operation order differ by about 1%. Tolerance: 3e-2 of the velocity scale
-    against both oracle builds."""
+    atlas, tests/test_oracle_physics.py::test_joint_limit_rows), so rounding is amplified there: a 1e-7
+    relative perturbation of the state moves the f64 result by 1e-4 of the velocity scale, and the f32 build
+    of the ORACLE (single common frame: differences of m r^2-sized terms) is 1.4 % off its f64 build on the
+    atlas / cervical joints. The kernel's body-local frames keep it at 2.1e-3 (scripts/limit_err.py).
+    Tolerance: 5e-3 of the velocity scale against the f64 oracle."""
     lo = model["q_lower"][model["obs_order"]]
     st = np.zeros((3, 63), np.float32)
     st[:, 2] = 50
@@ -179,12 +193,13 @@ def test_joint_limit_rows(oracle64, oracle32, model):
     oracle64.set_state(s, st[0].astype(np.float64))
     o, _, _ = oracle64.step(s, a[0].astype(np.float64))
     scale = np.abs(o[25:50]).max()
-    np.testing.assert_allclose(obs[0, :25], o[:25], atol=5e-4)
-    np.testing.assert_allclose(obs[0, 25:50], o[25:50], atol=3e-2 * scale)
+    np.testing.assert_allclose(obs[0, :25], o[:25], atol=1e-4 + 0.01 * 5e-3 * scale)
+    np.testing.assert_allclose(obs[0, 25:50], o[25:50], atol=5e-3 * scale)
     s32 = oracle32.new_state()
     oracle32.set_state(s32, st[0].astype(np.float64))
     o32, _, _ = oracle32.step(s32, a[0].astype(np.float64))
-    np.testing.assert_allclose(obs[0, 25:50], o32[25:50], atol=3e-2 * scale)
+    # the kernel is closer to the f64 oracle than the oracle's own f32 build is
+    assert np.abs(obs[0, 25:50] - o[25:50]).max() < np.abs(o32[25:50] - o[25:50]).max()
     assert np.all(obs[0, :25] > lo - 0.05)
 
 
@@ -364,6 +379,54 @@ def test_reward_is_the_reference_formula(full):
     want = -1.0 * (2.5 - head[:, 2]) ** 2 - 0.002 * (head[:, 0] ** 2 + head[:, 1] ** 2) - 0.005 * power
     assert torch.allclose(rew.double(), want, rtol=2e-4, atol=1e-3)
     assert torch.allclose(v.penalties.double().sum(1), -rew.double(), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("params", [dict(contact_margin=0.5), dict(max_contacts=4)])
+def test_more_touching_bodies_than_contact_rows(model, params):
+    """17 bodies inside an inflated margin against the 13-point budget, and 7 touching bodies against a budget of 4:
+    the rows go to the deepest bodies, in the kernel as in the oracle. One-step parity along the landing, contact
+    counts equal, and after the landing no hull vertex more than 2 cm below the floor."""
+    from oracle import oracle as O
+    orc = O.Oracle(model, params=params)
+    q0 = model["q_start"][model["obs_order"]].astype(np.float32)
+    s = orc.new_state()
+    orc.reset(s)
+    states = []
+    for t in range(150):
+        orc.step(s, q0.astype(np.float64))
+        if t % 5 == 4:
+            states.append(orc.get_state(s).astype(np.float32))
+    states = np.array(states)
+    v = make_vec(len(states), params=params)
+    v.reset()
+    v.set_state(torch.tensor(states))
+    acts = np.tile(q0, (len(states), 1))
+    obs, rew, _, _ = v.step(acts)
+    cnt = torch.zeros(len(states), dtype=torch.int32, device=DEV)
+    v.batch.contact_stats(cnt, None)
+    budget = int(params.get("max_contacts", 13))
+    over = 0
+    for t in range(len(states)):
+        s2 = orc.new_state()
+        orc.set_state(s2, states[t].astype(np.float64))
+        o, r, _ = orc.step(s2, q0.astype(np.float64))
+        # (4 rows for 7 touching bodies is not a consistent support - the supporting set rotates, the ground force
+        # jitters around 1.2 x the weight, tests/test_oracle_physics.py - and amplifies rounding: 2x the rate tolerance)
+        assert_step_close(obs[t], o, rew[t], r, "budget state %d" % t, loosen=2.0 if budget < 7 else 1.0)
+        assert cnt[t].item() == len(orc.contacts(s2)[0]) <= budget
+        over += cnt[t].item() == budget
+    assert over > 5                                   # the budget really was exhausted along the way
+    for _ in range(50):
+        v.step(acts)
+    st = v.get_state().cpu().numpy().astype(np.float64)
+    hs, hv = model["hull_start"], model["hull_xyz"]
+    for e in (0, len(states) // 2, len(states) - 1):
+        s3 = orc.new_state()
+        orc.set_state(s3, st[e])
+        pos, rot = orc.body_poses(s3)
+        low = min((pos[b][2] + (rot[b].reshape(3, 3) @ hv[hs[b]:hs[b + 1]].T)[2]).min()
+                  for b in range(model["nb"]) if hs[b + 1] > hs[b])
+        assert low > 0.0005 - 0.02
 
 
 def test_config4_size_on_one_gpu(oracle64, oracle32, model):

@@ -227,3 +227,48 @@ def test_f32_oracle_tracks_f64(model, oracle64, oracle32):
     np.testing.assert_allclose(o32[:50], o64[:50], atol=2e-4)
     np.testing.assert_allclose(o32[50:], o64[50:], atol=2e-2 * max(1.0, np.abs(o64[50:]).max()))
     assert abs(r32 - r64) < 1e-3 * abs(r64)
+
+
+def _lowest_hull_vertex(model, orc, s):
+    pos, rot = orc.body_poses(s)
+    hs, hv = model["hull_start"], model["hull_xyz"]
+    z = [(pos[b][2] + (rot[b].reshape(3, 3) @ hv[hs[b]:hs[b + 1]].T)[2]).min() for b in range(model["nb"]) if hs[b + 1] > hs[b]]
+    return min(z)
+
+
+def _settle(model, steps=400, **params):
+    orc = O.Oracle(model, params=params)
+    s = orc.new_state()
+    orc.reset(s)
+    q0 = model["q_start"][model["obs_order"]]
+    bodies = 0
+    for _ in range(steps):
+        orc.step(s, q0)
+        bodies = max(bodies, len(set(orc.contacts(s)[0].astype(int))))
+    lam = orc.contacts(s)[1]
+    weight = lam[:, 0].sum() / 0.002 / (model["mass"].sum() * 9.81)
+    return orc, s, orc.get_state(s), bodies, weight
+
+
+def test_contact_budget_degrades_gracefully(model):
+    """More touching bodies than contact rows: the budget goes to the DEEPEST bodies (oracle and kernel alike), so
+    no body sinks for lack of a row. Quantified against an effectively unbudgeted run (64 points):
+      * the headline budget (13) at the standard margin: rest height within 0.5 mm, ground carries the weight to 1 %
+      * 17 bodies inside an inflated 0.5 m margin, budget 13: the same rest pose to 0.5 mm, nothing below the floor
+      * budget 4 with 7 bodies touching: the supporting set rotates (jitter: weight within 35 %), yet nothing sinks
+        (lowest vertex within 5 mm of the floor) and the rest height stays within 5 mm."""
+    floor = 0.0005
+    _, _, ref, bodies64, w64 = _settle(model, max_contacts=64)
+    assert bodies64 >= 7 and abs(w64 - 1) < 0.01
+    orc, s, st, _, w = _settle(model, max_contacts=13)
+    assert abs(st[2] - ref[2]) < 5e-4 and abs(w - 1) < 0.01
+    orc, s, st, bodies, w = _settle(model, max_contacts=13, contact_margin=0.5)
+    assert len(orc.contacts(s)[0]) == 13                       # budget exhausted, one point per kept body
+    orc64, s64, st64, bodies_all, _ = _settle(model, max_contacts=64, contact_margin=0.5)
+    assert bodies_all > 13                                       # more bodies inside the margin than rows
+    assert abs(st[2] - st64[2]) < 5e-4 and abs(w - 1) < 0.01
+    assert _lowest_hull_vertex(model, orc, s) > floor - 1e-3
+    orc, s, st, bodies, w = _settle(model, max_contacts=4)
+    assert len(orc.contacts(s)[0]) == 4
+    assert _lowest_hull_vertex(model, orc, s) > floor - 5e-3
+    assert abs(st[2] - ref[2]) < 5e-3 and abs(w - 1) < 0.35
