@@ -146,7 +146,13 @@ def main():
     under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
     if world > 1 or under_launcher:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # "nccl" IS RCCL on ROCm. TREX_BENCH_BACKEND=gloo: rehearsal of the N>1 control flow with several ranks on
+        # ONE GPU (RCCL refuses two ranks per device); never a measurement.
+        backend = os.environ.get("TREX_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     rccl_ranks = dist.get_world_size() if dist.is_initialized() else 1
 
     n_global = args.envs_per_gpu * world

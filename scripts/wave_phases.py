@@ -41,7 +41,10 @@ def main():
     cnt = torch.zeros(n, dtype=torch.int32, device=dev)
     b.contact_stats(cnt, None)
     c = cnt.cpu().numpy()
-    d = dbg.cpu().numpy()[4096:4096 + 9 * n].reshape(9, n)
+    raw = dbg.cpu().numpy()[4096:4096 + 11 * n].reshape(11, n)
+    d = raw[:9].copy()
+    sub = raw[9:11]                      # contact generation split: [small-hull scan, large-hull scan]; d[1] = the rest
+    d[1] += sub.sum(0)
     tot = d.sum(0)
     print("waves %d, contacts per env mean %.2f max %d" % (n, c.mean(), c.max()))
     print("wave cycles: mean %.3g  median %.3g  p90 %.3g  p99 %.3g  max %.3g  (max/mean %.2f)" % (
@@ -50,12 +53,27 @@ def main():
     print("%-36s %12s %7s %14s" % ("phase", "mean cycles", "share", "slowest 1 %"))
     for k, name in enumerate(NAMES):
         print("%-36s %12.0f %6.1f %% %14.0f" % (name, d[k].mean(), 100 * d[k].mean() / tot.mean(), d[k][slow].mean()))
+    print("contact generation = broad phase + small-hull scan %.0f + large-hull scan %.0f + point selection %.0f (slowest 1 %%: %.0f + %.0f + %.0f)" % (
+        sub[0].mean(), sub[1].mean(), (d[1] - sub.sum(0)).mean(), sub[0][slow].mean(), sub[1][slow].mean(), (d[1] - sub.sum(0))[slow].mean()))
     for lo_, hi_ in ((0, 0), (1, 4), (5, 8), (9, 13)):
         sel = (c >= lo_) & (c <= hi_)
         if sel.any():
             rows = 25 + 3 * c[sel].mean()
             print("envs with %2d..%2d contacts: %5d  wave cycles mean %.3g max %.3g; sweeps mean %.3g = %.1f cycles per row visit" % (
                 lo_, hi_, sel.sum(), tot[sel].mean(), tot[sel].max(), d[7][sel].mean(), d[7][sel].mean() / (300 * rows)))
+
+
+    # (the diagnostic launch is not balanced: workgroup k = env k, and workgroup k shares its SIMD with k +- 1024 ...)
+    if n == 4096:
+        order = np.argsort(tot)[::-1][:8]
+        print("slowest waves: cycles, contacts | sweeps, contact gen, pass 2, B build | SIMD mates' (cycles, contacts)")
+        for w in order:
+            mates = [(w + 1024 * k) % 4096 for k in (1, 2, 3)]
+            print("  %.3g %2d | %.3g %.3g %.3g %.3g | %s" % (tot[w], c[w], d[7][w], d[1][w], d[3][w], d[6][w],
+                  " ".join("(%.3g, %d)" % (tot[m_], c[m_]) for m_ in mates)))
+        simd = tot.reshape(4, 1024)
+        print("per-SIMD (k mod 1024): sum of its 4 waves' cycles mean %.3g max %.3g; max of its 4 waves mean %.3g max %.3g" % (
+            simd.sum(0).mean(), simd.sum(0).max(), simd.max(0).mean(), simd.max(0).max()))
 
 
 if __name__ == "__main__":

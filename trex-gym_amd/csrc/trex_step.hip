@@ -65,8 +65,11 @@
     stamp_last = _t;                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                    \
   } while (0)
+// sub-phase stamp inside a phase: adds the cycles since the last stamp to slot i, then continues the phase clock
+#define SUBSTAMP(i) STAMP(i)
 #else
 #define STAMP(i) asm volatile("; ---- phase mark " #i)
+#define SUBSTAMP(i) do {} while (0)
 #endif
 
 namespace {
@@ -375,10 +378,15 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
   // many contact rows. During its sweeps such a wave wins the issue arbitration against the lighter waves of
   // its SIMD, which fill the slots its dependency chain leaves empty. (Mode 2, priority for the whole substep,
   // starved the light waves instead: 3.84 M against 4.12 M env-steps/s.)
+#ifndef TREX_PRIO_T1
+#define TREX_PRIO_T1 3
+#define TREX_PRIO_T2 6
+#define TREX_PRIO_T3 10
+#endif
   auto set_priority = [](int contacts) {
-    if (contacts >= 10) __builtin_amdgcn_s_setprio(3);
-    else if (contacts >= 6) __builtin_amdgcn_s_setprio(2);
-    else if (contacts >= 3) __builtin_amdgcn_s_setprio(1);
+    if (contacts >= TREX_PRIO_T3) __builtin_amdgcn_s_setprio(3);
+    else if (contacts >= TREX_PRIO_T2) __builtin_amdgcn_s_setprio(2);
+    else if (contacts >= TREX_PRIO_T1) __builtin_amdgcn_s_setprio(1);
     else __builtin_amdgcn_s_setprio(0);
   };
 #if TREX_PRIO_MODE == 2
@@ -446,6 +454,9 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
     bool is_body, is_joint;
 #define RELANE() do { lt = lane_id(); bl = lt & (TL - 1); is_body = lt < nb; is_joint = lt >= 1 && lt < nb; } while (0)
     RELANE();
+#if TREX_PRIO_MODE == 3
+    set_priority(sub == 0 ? uni(args.arr.contact_count[env]) : stat_nc);
+#endif
     int psrc, depth;
     {
       const TrexDeviceModel *Mi = Mo();
@@ -553,6 +564,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
         }
         active_mask |= (unsigned)__ballot(small && a_v >= 0);
       }
+      SUBSTAMP(9);    // broad phase + small-hull scan
       // (ii) large hulls (cranium, pelvis+ribcage): the wave strides over the vertices together
       unsigned near_mask = (unsigned)__ballot(near && !small);
       while (near_mask != 0u) {
@@ -600,6 +612,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
           }
         }
       }
+      SUBSTAMP(10);   // large-hull scan
       int n_active = __popc(active_mask);
       int K = n_active > 0 ? maxc / n_active : 0;
       K = K > 4 ? 4 : (K < 1 ? 1 : K);
@@ -731,6 +744,9 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
     nc = uni(nc);
 #if TREX_PRIO_MODE == 2
     set_priority(nc);
+#endif
+#if TREX_PRIO_MODE == 3
+    __builtin_amdgcn_s_setprio(0);
 #endif
     STAMP(1);
     RELANE();
@@ -1253,7 +1269,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
     // what is accumulated: it is small where lam is large, and the rounding of a row's own update stays in y.
     // Row order (the oracle's): limit rows (ascending joint), motor rows, then per point normal, friction x, y.
     float lam = 0.f, lim_lam = 0.f;
-#if TREX_PRIO_MODE == 1
+#if TREX_PRIO_MODE == 1 || TREX_PRIO_MODE == 3
     set_priority(nc);
 #endif
     {
@@ -1507,7 +1523,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
 #undef TREX_ROW
 #undef TREX_POINT
     }
-#if TREX_PRIO_MODE == 1
+#if TREX_PRIO_MODE == 1 || TREX_PRIO_MODE == 3
     __builtin_amdgcn_s_setprio(0);
 #endif
     STAMP(7);
