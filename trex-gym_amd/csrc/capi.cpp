@@ -1,6 +1,7 @@
 // C-ABI of include/trex_batch.h: model handle, batch handle, stream-ordered launches.
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -125,6 +126,43 @@ void fill_device_model(const trex::HostModel &h, TrexDeviceModel &d) {
     d.hull_start[b] = h.hull_start[b];
   }
   for (int b = h.nb; b <= TREX_TL; b++) d.hull_start[b] = h.hull_start[h.nb];
+  {
+    // scan units: the hull groups if they nest in the bodies' vertex ranges and are at most 32, else one per body
+    std::vector<std::array<int, 3>> units;   // body, v0, v1
+    bool ok = h.hull_group_start.size() >= 2;
+    if (ok)
+      for (size_t g = 0; g + 1 < h.hull_group_start.size() && ok; g++) {
+        const int g0 = h.hull_group_start[g], g1 = h.hull_group_start[g + 1];
+        if (g1 <= g0) continue;
+        int body = -1;
+        for (int b = 0; b < h.nb; b++)
+          if (h.hull_start[b] <= g0 && g1 <= h.hull_start[b + 1]) body = b;
+        if (body < 0) ok = false;
+        else units.push_back({body, g0, g1});
+      }
+    if (!ok || units.size() > TREX_TL) {
+      units.clear();
+      for (int b = 0; b < h.nb; b++)
+        if (h.hull_start[b + 1] > h.hull_start[b]) units.push_back({b, h.hull_start[b], h.hull_start[b + 1]});
+    }
+    d.nchunk = (int)units.size();
+    for (int k = 0; k < TREX_TL; k++) { d.chunk_body[k] = 0; d.chunk_v0[k] = 0; d.chunk_v1[k] = 0; }
+    for (size_t k = 0; k < units.size(); k++) {
+      const int v0 = units[k][1], v1 = units[k][2];
+      trex::Vec3 lo{1e300, 1e300, 1e300}, hi{-1e300, -1e300, -1e300};
+      for (int v = v0; v < v1; v++) {
+        const trex::Vec3 &p = h.hull_xyz[v];
+        const double r = h.hull_radius[v];
+        lo = {std::min(lo.x, p.x - r), std::min(lo.y, p.y - r), std::min(lo.z, p.z - r)};
+        hi = {std::max(hi.x, p.x + r), std::max(hi.y, p.y + r), std::max(hi.z, p.z + r)};
+      }
+      d.chunk_body[k] = units[k][0]; d.chunk_v0[k] = v0; d.chunk_v1[k] = v1;
+      d.chunk_c[0][k] = (float)(0.5 * (lo.x + hi.x)); d.chunk_c[1][k] = (float)(0.5 * (lo.y + hi.y)); d.chunk_c[2][k] = (float)(0.5 * (lo.z + hi.z));
+      // half extents rounded up: the bound must stay conservative in f32 (centre rounding included)
+      d.chunk_h[0][k] = (float)(0.5 * (hi.x - lo.x) * (1 + 1e-6) + 1e-6); d.chunk_h[1][k] = (float)(0.5 * (hi.y - lo.y) * (1 + 1e-6) + 1e-6);
+      d.chunk_h[2][k] = (float)(0.5 * (hi.z - lo.z) * (1 + 1e-6) + 1e-6);
+    }
+  }
   d.maxdepth = maxdepth;
   for (size_t k = 0; k < h.obs_order.size(); k++) d.obs_slot[h.obs_order[k]] = (int)k;
   // dof lane l in chain of body b?  joint lanes: b is l or a descendant of l; base dof lanes: every body

@@ -34,6 +34,13 @@ struct TrexDeviceModel {
   float mass[TREX_TL], lower[TREX_TL], upper[TREX_TL], damp[TREX_TL], q_start[TREX_TL];
   float sphere[4][TREX_TL];           /* bounding sphere of the body's hull vertices: cx cy cz r */
   float box_half[3][TREX_TL];         /* half extents of their body-frame AABB (same centre): the broad-phase bound */
+  /* Scan units of the contact generation: one per convex hull (28 for trex.urdf; the pelvis body carries 6), so that
+   * the broad phase tests - and the narrow phase scans - a hull, not everything merged into its body. At most 32
+   * (one lane each); a model with more hulls gets one unit per body. Vertices [v0, v1) of `hull`, body-frame AABB
+   * centre and half extents (support radius included). */
+  int nchunk, pad3[3];
+  int chunk_body[TREX_TL], chunk_v0[TREX_TL], chunk_v1[TREX_TL];
+  float chunk_c[3][TREX_TL], chunk_h[3][TREX_TL];
 };
 
 /* Per-env state in HBM. One row per env, padded so that a 32-lane team reads whole 128-B segments:

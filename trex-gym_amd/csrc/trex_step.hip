@@ -280,6 +280,14 @@ struct WaveLds {
 };
 enum { ST_Q, ST_QD, ST_TAU, ST_TARGET, ST_NQD, ST_MDG };
 static_assert(sizeof(WaveLds) <= 10240, "16 workgroups per CU need <= 10 KB of LDS each");
+// Contact generation works in the union area (the inertia slots are written after it):
+constexpr int CG_WORDS = 28;             // in-margin mask words per body: hulls of up to 896 vertices (pelvis: 840)
+struct CgLds {
+  unsigned long long best[TL];           // per body: min of (ordered distance << 32 | vertex)                256 B
+  float4 ent[TL][2];                     // near-hull table: end position | vertex - position | body | body v0 ; Rz, zb  1024 B
+  unsigned cm[TL][CG_WORDS];             // per body: bit i <-> vertex hull_start[body] + i inside the margin   3584 B
+};
+static_assert(sizeof(CgLds) <= sizeof(WaveLds::u), "contact-generation scratch fits the union area");
 
 struct KernelArgs {
   const TrexDeviceModel *model;
@@ -495,124 +503,118 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
     STAMP(0);
 
     // ================================================================ contact generation
-    // hull vertices against z <= floor_z. Pass A walks the near bodies once: it finds whether a body has any
-    // vertex inside the margin and, in the same sweep, its DEEPEST such vertex (= the first point the
-    // selection rule keeps), parked in lane b's registers, and - as bit masks - WHICH vertices are inside.
+    // hull vertices against z <= floor_z. Pass A finds, per body, WHICH vertices are inside the margin (bit masks
+    // in LDS) and its DEEPEST such vertex (= the first point the selection rule keeps):
+    //   * broad phase per HULL (scan unit), one lane each: the lowest point of the hull's oriented bounding box
+    //     (only the z row of the body's rotation is needed);
+    //   * the vertices of all near hulls form ONE list that the 64 lanes stride over together (lane l takes list
+    //     positions l, l + 64, ...; a cursor walks the near-hull table), 4 loads in flight per lane: two feet on
+    //     the ground are 700 vertices = 11 per lane, where a lane per body scanned up to 96 one after the other;
+    //   * results by LDS atomics, which commute: or into the body's mask, min of (distance, vertex) - ties go to
+    //     the lowest vertex index, as in the oracle.
     // Pass B revisits a body's in-margin vertices only when more than one point per body is kept (K >= 2).
     // The points go to LDS (W.cpt) in contact order; only their number nc stays in a register.
     int nc = 0;
     {
       const TrexDeviceModel *Mi = Mo();
       const int hull_v0 = Mi->hull_start[is_body ? lt : nb], hull_v1 = Mi->hull_start[is_body ? lt + 1 : nb];
-      float sc[3];
-      float sph[3], boxh[3];
+      CgLds &G = *reinterpret_cast<CgLds *>(&W.u);
+      // clear the masks and the minima
+      {
+        unsigned *z = &G.cm[0][0];
 #pragma unroll
-      for (int c = 0; c < 3; c++) { sph[c] = Mi->sphere[c][bl]; boxh[c] = Mi->box_half[c][bl]; }
-      matvec3(R, sph, sc);
-      // broad phase: lowest point of the hull's oriented bounding box (conservative, much tighter than
-      // a sphere for the long bones): z_centre - sum_k |R_zk| half_k
-      const float reach = fabsf(R[6]) * boxh[0] + fabsf(R[7]) * boxh[1] + fabsf(R[8]) * boxh[2];
-      const float zb = pos[2] + r[2] - floor_z;    // body origin above the floor
-      const bool near = is_body && hull_v1 > hull_v0 && (zb + sc[2] - reach < margin);
+        for (int i = 0; i < (TL * CG_WORDS + 63) / 64; i++)
+          if (lt + 64 * i < TL * CG_WORDS) z[lt + 64 * i] = 0u;
+        if (lt < TL) G.best[lt] = ~0ull;
+      }
+      // ---- broad phase, one hull per lane
+      const int nchunk = Mi->nchunk;
+      const bool is_chunk = lt < nchunk;
+      const int cbody = Mi->chunk_body[bl], cv0 = Mi->chunk_v0[bl], cv1 = is_chunk ? Mi->chunk_v1[bl] : 0;
+      float Rz[3], zbc;
+      {
+        const float zb = pos[2] + r[2] - floor_z;    // body origin above the floor (body lanes)
+#pragma unroll
+        for (int c = 0; c < 3; c++) Rz[c] = wshfl(R[6 + c], cbody);
+        zbc = wshfl(zb, cbody);
+      }
+      bool near = false;
+      if (is_chunk) {
+        const float cz = Rz[0] * Mi->chunk_c[0][bl] + Rz[1] * Mi->chunk_c[1][bl] + Rz[2] * Mi->chunk_c[2][bl];
+        const float reach = fabsf(Rz[0]) * Mi->chunk_h[0][bl] + fabsf(Rz[1]) * Mi->chunk_h[1][bl] + fabsf(Rz[2]) * Mi->chunk_h[2][bl];
+        near = cv1 > cv0 && (zbc + cz - reach < margin);
+      }
+      const unsigned near_mask = (unsigned)__ballot(near);
+      // ---- table of the near hulls: position of their first vertex in the list, ... (prefix sum over the set bits)
+      int total = 0;
+      {
+        int my_off = 0;
+        for (unsigned m = near_mask; m != 0u; m &= m - 1u) {
+          const int k = __ffs(m) - 1;
+          if (lt == k) my_off = total;
+          total += rl(cv1 - cv0, k);
+        }
+        if (near) {
+          const int e = __popc(near_mask & ((1u << bl) - 1u));
+          G.ent[e][0] = make_float4(__int_as_float(my_off + (cv1 - cv0)), __int_as_float(cv0 - my_off),
+                                    __int_as_float(cbody), __int_as_float(Mi->hull_start[cbody]));
+          G.ent[e][1] = make_float4(Rz[0], Rz[1], Rz[2], zbc);
+        }
+      }
+      __syncthreads();
+      SUBSTAMP(9);    // broad phase + table
+      // ---- the scan
+      if (total > 0) {
+        int cur = 0;
+        float4 e0 = G.ent[0][0], e1 = G.ent[0][1];
+        constexpr int UN = 4;
+        for (int f0 = 0; f0 < total; f0 += 64 * UN) {
+          float4 h[UN], q[UN];
+          int vtx[UN], rel[UN], bod[UN];
+#pragma unroll
+          for (int u = 0; u < UN; u++) {
+            const int f = f0 + 64 * u + lt;
+            // advance the cursor to the hull that holds list position f (hulls hold >= 1 vertex: a few steps at most)
+            while (f < total && f >= __float_as_int(e0.x)) { cur++; e0 = G.ent[cur][0]; e1 = G.ent[cur][1]; }
+            vtx[u] = f < total ? f + __float_as_int(e0.y) : -1;
+            bod[u] = __float_as_int(e0.z);
+            rel[u] = vtx[u] - __float_as_int(e0.w);
+            q[u] = e1;
+            h[u] = args.arr.hull[vtx[u] < 0 ? 0 : vtx[u]];
+          }
+#pragma unroll
+          for (int u = 0; u < UN; u++) {
+            // only the height decides; h.w = support radius (0 for a hull vertex): the sphere's lowest point
+            const float dd = q[u].w + (q[u].x * h[u].x + q[u].y * h[u].y + q[u].z * h[u].z) - h[u].w;
+            if (vtx[u] >= 0 && dd < margin) {
+              if (rel[u] < 32 * CG_WORDS) atomicOr(&G.cm[bod[u]][rel[u] >> 5], 1u << (rel[u] & 31));
+              unsigned ub = __float_as_uint(dd);
+              ub ^= (ub >> 31) ? 0xffffffffu : 0x80000000u;    // order-preserving map of the float to unsigned
+              atomicMin(&G.best[bod[u]], ((unsigned long long)ub << 32) | (unsigned)vtx[u]);
+            }
+          }
+        }
+      }
+      __syncthreads();
+      SUBSTAMP(10);   // scan
+      // ---- per body: its deepest vertex
       unsigned active_mask = 0u;
       float a_x[3] = {0.f, 0.f, 0.f}, a_d = 0.f;   // lane b: deepest candidate of body b
       int a_v = -1;
-      // (i) small hulls (<= 96 vertices: every foot, shank, neck and tail segment): the BODY LANE scans its
-      // own vertices serially with its own R, r - all near bodies in parallel, no shuffles, no reductions.
-      constexpr int SMALL_HULL = 96;
-      const int nverts = hull_v1 - hull_v0;
-      const bool small = near && nverts <= SMALL_HULL;
-      // In-margin vertex sets, kept for the point selection (pass B never sweeps a hull again): a small body's
-      // lane keeps bit i of cm[i / 32] for its vertex i; for the (at most two) large bodies every lane keeps
-      // bit i for its strided vertex v0 + lane + 64 i.
-      unsigned cm0 = 0u, cm1 = 0u, cm2 = 0u;
-      unsigned imL0 = 0u, imL1 = 0u;
-      int bL0 = -1, bL1 = -1;
-      if (__ballot(small) != 0ull) {
-        float bs = -3.0e38f;
-        constexpr int UN = 8;   // independent 16-B loads in flight per lane
-        for (int i0 = 0; __ballot(small && i0 < nverts) != 0ull; i0 += UN) {
-          unsigned bm = 0u;
-          float4 h[UN];
-#pragma unroll
-          for (int u = 0; u < UN; u++) {
-            const int i = min(i0 + u, nverts - 1);
-            h[u] = args.arr.hull[hull_v0 + (small ? max(i, 0) : 0)];
-          }
-#pragma unroll
-          for (int u = 0; u < UN; u++) {
-            const int i = i0 + u;
-            // only the height decides; the winner's position is formed once, after the scan.
-            // h.w = support radius (0 for a hull vertex): the contact point is the sphere's lowest point
-            const float wz = R[6] * h[u].x + R[7] * h[u].y + R[8] * h[u].z;
-            const float dd = zb + wz - h[u].w;
-            const bool in = small && i < nverts && dd < margin;
-            bm |= in ? (1u << u) : 0u;
-            if (in && -dd > bs) { bs = -dd; a_v = hull_v0 + i; a_d = dd; }
-          }
-          const unsigned add = bm << (i0 & 24);
-          if ((i0 >> 5) == 0) cm0 |= add;
-          else if ((i0 >> 5) == 1) cm1 |= add;
-          else cm2 |= add;
-        }
-        if (small && a_v >= 0) {
+      {
+        const unsigned long long key = lt < TL ? G.best[bl] : ~0ull;
+        if (is_body && key != ~0ull) {
+          a_v = (int)(unsigned)(key & 0xffffffffull);
           const float4 hw = args.arr.hull[a_v];
           const float hv[3] = {hw.x, hw.y, hw.z};
           float w[3];
           matvec3(R, hv, w);
           a_x[0] = r[0] + w[0]; a_x[1] = r[1] + w[1]; a_x[2] = r[2] + w[2] - hw.w;
+          a_d = pos[2] + a_x[2] - floor_z;
         }
-        active_mask |= (unsigned)__ballot(small && a_v >= 0);
+        active_mask = (unsigned)__ballot(a_v >= 0);
       }
-      SUBSTAMP(9);    // broad phase + small-hull scan
-      // (ii) large hulls (cranium, pelvis+ribcage): the wave strides over the vertices together
-      unsigned near_mask = (unsigned)__ballot(near && !small);
-      while (near_mask != 0u) {
-        const int b = __ffs(near_mask) - 1;
-        near_mask &= near_mask - 1u;
-        float Rb[3], rbz;     // only the z row and z origin decide
-#pragma unroll
-        for (int c = 0; c < 3; c++) Rb[c] = rl(R[6 + c], b);
-        rbz = rl(zb, b);
-        const int v0 = rl(hull_v0, b), v1 = rl(hull_v1, b);
-        float bs = -3.0e38f;
-        int bi = 0x7fffffff;
-        unsigned im = 0u;
-        constexpr int UL = 4;   // 4 coalesced 1-KB loads in flight per wave
-        for (int it0 = 0; v0 + 64 * it0 < v1; it0 += UL) {
-          float4 h[UL];
-#pragma unroll
-          for (int u = 0; u < UL; u++) {
-            const int v = v0 + lt + 64 * (it0 + u);
-            h[u] = args.arr.hull[v < v1 ? v : v0];
-          }
-#pragma unroll
-          for (int u = 0; u < UL; u++) {
-            const int v = v0 + lt + 64 * (it0 + u);
-            const float wz = Rb[0] * h[u].x + Rb[1] * h[u].y + Rb[2] * h[u].z;   // the height decides
-            const float dd = rbz + wz - h[u].w;
-            if (v < v1 && dd < margin) {
-              im |= (it0 + u < 32) ? (1u << (it0 + u)) : 0u;
-              if (-dd > bs) { bs = -dd; bi = v; }
-            }
-          }
-        }
-        if (bL0 < 0) { bL0 = b; imL0 = im; }
-        else if (bL1 < 0) { bL1 = b; imL1 = im; }
-        wargmax(bs, bi);
-        if (bi != 0x7fffffff) {   // position of the deepest vertex, formed once by the body's own lane
-          active_mask |= 1u << b;
-          if (lt == b) {
-            const float4 hw = args.arr.hull[bi];
-            const float hv[3] = {hw.x, hw.y, hw.z};
-            float w[3];
-            matvec3(R, hv, w);
-            a_x[0] = r[0] + w[0]; a_x[1] = r[1] + w[1]; a_x[2] = r[2] + w[2] - hw.w;
-            a_d = -bs; a_v = bi;
-          }
-        }
-      }
-      SUBSTAMP(10);   // large-hull scan
+      constexpr int SMALL_HULL = 96;
       int n_active = __popc(active_mask);
       int K = n_active > 0 ? maxc / n_active : 0;
       K = K > 4 ? 4 : (K < 1 ? 1 : K);
@@ -654,15 +656,14 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
           for (int c = 0; c < 3; c++) rb[c] = rl(r[c], b);
           const int v0 = rl(hull_v0, b), v1 = rl(hull_v1, b);
           // this lane's candidates of body b: bit i <-> vertex v0 + lane + 64 i (in the margin during pass A)
-          unsigned im;
-          const bool masked = (v1 - v0) <= 2048 && ((v1 - v0) <= SMALL_HULL || b == bL0 || b == bL1);
-          if ((v1 - v0) <= SMALL_HULL) {
-            const unsigned c0 = rl(cm0, b), c1 = rl(cm1, b), c2 = rl(cm2, b);
-            im = (lt < 32) ? (((c0 >> bl) & 1u) | (((c2 >> bl) & 1u) << 1)) : ((c1 >> bl) & 1u);
+          unsigned im = 0u;
+          const bool masked = (v1 - v0) <= 32 * CG_WORDS;
+          if (masked) {
+            const int nw2 = ((v1 - v0) + 63) >> 6;     // vertices per lane
+            for (int i = 0; i < nw2; i++) im |= ((G.cm[b][2 * i + (lt >> 5)] >> (lt & 31)) & 1u) << i;
           } else {
-            im = (b == bL0) ? imL0 : ((b == bL1) ? imL1 : 0xffffffffu);
+            im = 0xffffffffu;   // a hull beyond the mask capacity: sweep it
           }
-          if (!masked) im = 0xffffffffu;   // (a third large hull, or one beyond 2048 vertices: sweep it)
           {
             const int o = sel[0] - v0;     // the deepest vertex is taken
             if (lt == (o & 63) && (o >> 6) < 32) im &= ~(1u << (o >> 6));
@@ -1514,7 +1515,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
           lam += __int_as_float(dvec);
         }
         // the live point slots, in order (dead slots have no bit in `alive`)
-        unsigned long long alive = alive_points();
+        unsigned long long alive = nrm_mask != 0ull ? alive_points() : 0ull;   // (an airborne env has no point rows at all)
         if (alive != 0ull) {
           TREX_POINT(0) TREX_POINT(1) TREX_POINT(2) TREX_POINT(3) TREX_POINT(4) TREX_POINT(5) TREX_POINT(6)
           TREX_POINT(7) TREX_POINT(8) TREX_POINT(9) TREX_POINT(10) TREX_POINT(11) TREX_POINT(12)
