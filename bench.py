@@ -12,9 +12,9 @@ RCCL all-gather of the [obs | reward | done] row block (the path's only collecti
 
 The timed window is STATIONARY: episode phases are staggered (env i's 1000-step episode starts
 i*1000/N steps after env 0's), an untimed pre-roll of one full episode length brings every env to a
-different age, and the same schedule (a masked reset of the ~N/1000 envs whose episode ends) runs in
-every step, so any --steps / --warmup times the same mix of free fall, touchdown and flailing on the
-ground. `state_mix` in the JSON line holds the contact-count histogram at both ends of the window.
+different age, and in every step the ~N/1000 envs whose episode ends are reset inside the step launch
+(trex_batch_set_episode_limit), so any --steps / --warmup times the same mix of free fall, touchdown and
+flailing on the ground. `state_mix` in the JSON line holds the contact-count histogram at both ends of the window.
 
 The JSON line carries `roofline` (algorithmic 912 B/env-step over the kernel's hipEvent-timed
 duration vs the 8 TB/s HBM peak; the kernel is latency/VALU bound so the fraction is tiny - see
@@ -157,7 +157,8 @@ def main():
 
     n_global = args.envs_per_gpu * world
     overrides = {k: float(v) for k, v in (p.split("=") for p in args.param)}
-    env = TrexVecEnv(n_global, device=dev, rank=rank, world_size=world, params=overrides, collision=args.collision)
+    env = TrexVecEnv(n_global, device=dev, rank=rank, world_size=world, params=overrides, collision=args.collision,
+                     max_episode_steps=EPISODE_STEPS)
     if args.collision != "hulls":
         overrides = dict(overrides, collision=args.collision)
     n_local = env.num_envs
@@ -171,15 +172,6 @@ def main():
     pool = torch.stack([sharding.synthetic_actions(ids, t, mid - half, mid + half, seed=0, device=dev) for t in range(16)])
     if args.action_scale != 1.0:
         overrides = dict(overrides, action_scale=args.action_scale)
-    # staggered episodes, keyed by the GLOBAL env id: env i is reset at the steps t with
-    # (t + phase_i) % EPISODE_STEPS == 0. One uint8 mask per residue, built once (no per-step torch glue).
-    phase = (ids * EPISODE_STEPS) // n_global
-    reset_masks = [None] * EPISODE_STEPS
-    for k in range(EPISODE_STEPS):
-        m = (phase == k)
-        if bool(m.any().item()):
-            reset_masks[k] = m.to(torch.uint8).contiguous()
-
     events = []
     force_gather = under_launcher and world == 1 and bool(os.environ.get("TREX_BENCH_FORCE_GATHER"))
     pipe = (sharding.PipelinedGather(env.num_envs, env.rows.shape[1], 1, env.rows.dtype, dev) if force_gather else None)
@@ -194,9 +186,6 @@ def main():
             if timed:
                 e1.record()
                 events.append((e0, e1))
-            mk = reset_masks[(-(t_base + t + 1)) % EPISODE_STEPS]
-            if mk is not None:
-                env.reset_tensor(mk)      # episode limit of the harness: ~N/1000 envs per step
             if world > 1:
                 if gather_mode[0] == "pipelined":
                     env.all_gather_rows_pipelined()   # overlaps the next step; consumer sees rows one step late
@@ -218,6 +207,9 @@ def main():
         return [int(x) for x in h.tolist()[:14]]
 
     env.reset_tensor()
+    # staggered episodes, keyed by the GLOBAL env id: env i starts i * EPISODE_STEPS / N steps into its episode, so
+    # that in every step about N / EPISODE_STEPS envs reach the limit and are reset INSIDE the step launch
+    env.set_episode_steps(((ids * EPISODE_STEPS) // n_global).to(torch.int32))
     run(args.preroll, 0)
     t_base = args.preroll
     blocking_ms = None
@@ -298,8 +290,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": "trex_step_kernel<false, false>", "kernel_ms": kernel_ms,
-                         "kernel_ms_covers": "one step launch (balance kernel, about 7 us, + trex_step_kernel<false, false>), "
-                                             "bracketed by HIP events; the masked episode-limit reset launch is outside it",
+                         "kernel_ms_covers": "one step launch (balance kernel, about 6 us, + trex_step_kernel<false, false>, "
+                                             "which also resets the envs whose episode ends), bracketed by HIP events",
                          "alg_bytes_per_launch": alg, "kernel_build": build_id,
                          "note": "latency/VALU-bound by construction (serial PGS); HBM fraction reported as "
                                  "BASELINE asks, roofline_issue is the bound that matters (DESIGN.md)"},

@@ -119,7 +119,8 @@ int trex_batch_reset(TrexBatch *batch, const uint8_t *mask_dev, float *obs_out_d
  *   obs_dev       [N, 3J] f32 device: q, qd, appliedJointMotorTorque (trex_robot.py:365)
  *   reward_dev    [N]     f32 device (trex_env.py:192)
  *   done_dev      [N]     u8 device, 0 (trex_env.py:183-184) - except 1 for an env whose state became
- *                         non-finite: it is put back on the start pose and reports reward 0 (containment)
+ *                         non-finite (it is put back on the start pose and reports reward 0: containment) and
+ *                         for an env that reached the episode limit (trex_batch_set_episode_limit)
  *   penalties_dev [N, 3]  f32 device, nullable: lifting_com, station_keeping, energy
  *                         (the three values logged at trex_env.py:193-195) */
 int trex_batch_step(TrexBatch *batch, const float *actions_dev, float *obs_dev, float *reward_dev,
@@ -132,6 +133,16 @@ int trex_batch_step(TrexBatch *batch, const float *actions_dev, float *obs_dev, 
 int trex_batch_step_rows(TrexBatch *batch, const float *actions_dev, float *rows_dev, int row_stride,
                          float *penalties_dev, void *stream);
 int trex_batch_reset_rows(TrexBatch *batch, const uint8_t *mask_dev, float *rows_dev, int row_stride, void *stream);
+
+/* Episode limit of the harness. The reference env never terminates (should_terminate() is constant False,
+ * trex_env.py:183-184); a training harness cuts episodes (gym's TimeLimit; baselines' VecEnv then resets the env
+ * and returns the first observation of the new episode with done = True). With max_episode_steps > 0 the STEP
+ * LAUNCH itself does that for the envs whose step count reaches the limit: reward of the finished step, done = 1,
+ * then start pose + the reset's settle substep, observation of the new episode - no separate reset launch.
+ * episode_steps_dev ([N] i32, nullable = zeros) sets the counts (e.g. to stagger the episodes);
+ * max_episode_steps = 0 switches the limit off. trex_batch_reset zeroes the count of the envs it resets. */
+int trex_batch_set_episode_limit(TrexBatch *batch, int max_episode_steps, const int32_t *episode_steps_dev, void *stream);
+int trex_batch_get_episode_steps(TrexBatch *batch, int32_t *episode_steps_dev, void *stream);
 
 /* env state [N, 13 + 2J] f32 device: base position(3), base orientation quaternion xyzw(4) - both
  * of the base INERTIAL frame as resetBasePositionAndOrientation/getBasePositionAndOrientation

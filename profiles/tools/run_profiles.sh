@@ -1,12 +1,23 @@
 #!/bin/bash
 # Round profile set for bench.py (run on the GPU box from the repo root):
-#   1. kernel trace + stats   2. HBM traffic PMC passes (+ calibration)   3. SQ instruction/occupancy PMC pass
+#   1. kernel trace + stats   2. HBM traffic PMC passes (+ calibration)   3. SQ instruction/occupancy PMC passes
+#   4. per-wave phase cycles of the diagnostic build   5. the plain bench lines (300 and 20 timed steps)
+# scripts/refresh_profiles.py <tag> then turns gpurun_out/ into profiles/<tag>_* (+ sq_counters.json, pmc_traffic.json)
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof
 rm -rf $OUT gpurun_out/pmc && mkdir -p $OUT
+python bench.py --steps 300 --warmup 30 > $OUT/bench_300.json 2> $OUT/bench_300.err
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_20.json 2> $OUT/bench_20.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --steps 200 --warmup 30 --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/bench_trace.err
 bash profiles/tools/run_pmc.sh > $OUT/pmc.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $OUT/sq -- python bench.py --steps 40 --warmup 30 --no-cpu-baseline > $OUT/bench_sq.json 2> $OUT/bench_sq.err || echo "SQ pass failed"
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/sq2 -- python bench.py --steps 40 --warmup 30 --no-cpu-baseline > $OUT/bench_sq2.json 2> $OUT/bench_sq2.err || echo "SQ2 pass failed"
-ls $OUT
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS --output-format csv -d $OUT/sq2 -- python bench.py --steps 40 --warmup 30 --no-cpu-baseline > $OUT/bench_sq2.json 2> $OUT/bench_sq2.err || echo "SQ2 pass failed"
+TREX_LIB=$PWD/trex-gym_amd/trex_gym/libtrex_hip_stamps.so python scripts/wave_phases.py 4096 300 2>&1 | grep -v amdgpu.ids > $OUT/wave_phases_4096.txt
+TREX_LIB=$PWD/trex-gym_amd/trex_gym/libtrex_hip_stamps.so python scripts/wave_phases.py 256 300 2>&1 | grep -v amdgpu.ids > $OUT/wave_phases_256.txt
+./profiles/tools/row_bench > $OUT/row_bench.txt 2>&1 || true
+./profiles/tools/census 4096 > $OUT/census.txt 2>&1 || true
+# summarise on the box (the raw traces are too big to travel), keep only gpurun_out/prof/final
+python scripts/refresh_profiles.py ${1:-r02} $OUT/final
+rm -rf $OUT/trace $OUT/sq $OUT/sq2 gpurun_out/pmc
+ls $OUT/final

@@ -29,13 +29,19 @@ def main():
     timed = d[-steps:]
     lines += ["", "step kernel `trex_step_kernel<false, false>`: %d dispatches; timed region (last %d): avg %.3f ms, min %.3f, max %.3f"
               % (len(d), len(timed), sum(timed) / len(timed) / 1e6, min(timed) / 1e6, max(timed) / 1e6)]
-    pk = [r for r in csv.DictReader(open(trace)) if "trex_pair_kernel" in r["Kernel_Name"]]
+    pk = [r for r in csv.DictReader(open(trace)) if "trex_balance_kernel" in r["Kernel_Name"]]
     if pk:
         pk.sort(key=lambda r: int(r["Start_Timestamp"]))
         pd = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in pk][-steps:]
-        lines.append("`trex_pair_kernel` (wave pairing, launched before every step kernel): timed region avg %.4f ms; "
-                     "step launch = pair + step = %.3f ms (bench.py brackets exactly this with HIP events)"
+        lines.append("`trex_balance_kernel` (wave balance by contact rank, launched before every step kernel): timed region avg "
+                     "%.4f ms; step launch = balance + step = %.3f ms (bench.py brackets exactly this with HIP events)"
                      % (sum(pd) / len(pd) / 1e6, (sum(pd) / len(pd) + sum(timed) / len(timed)) / 1e6))
+    rs = [r for r in csv.DictReader(open(trace)) if "trex_step_kernel<true, false>" in r["Kernel_Name"]]
+    if rs:
+        rs.sort(key=lambda r: int(r["Start_Timestamp"]))
+        rd = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rs][-steps:]
+        lines.append("`trex_step_kernel<true, false>` (masked episode-limit reset of about N/1000 envs per step, outside the "
+                     "HIP-event bracket): timed region avg %.4f ms" % (sum(rd) / len(rd) / 1e6))
     r0 = t[-1]
     keys = [k for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size") if k in r0]
     lines.append("dispatch: " + ", ".join("%s=%s" % (k, r0[k]) for k in keys))

@@ -504,6 +504,33 @@ def test_time_limit_auto_reset():
     assert not done.any()
 
 
+def test_episode_limit_inside_the_step_launch():
+    """trex_batch_set_episode_limit: the env whose count reaches the limit is reset BY THE STEP LAUNCH - reward of the
+    finished step, done = 1, observation of the new episode (baselines' VecEnv semantics) - and equals an explicit
+    reset bitwise; staggered counts end the episodes in different steps; the other envs are untouched."""
+    a = torch.zeros(4, 25, device=DEV)
+    v = make_vec(4, max_episode_steps=5)
+    first = v.reset_tensor().clone()
+    v.set_episode_steps(torch.tensor([4, 3, 0, 0], dtype=torch.int32))
+    ref = make_vec(4)                      # no limit: the same physics without resets
+    ref.reset_tensor()
+    o, r, d = v.step_tensor(a)
+    o0, r0, _ = ref.step_tensor(a)
+    assert d.tolist() == [True, False, False, False]
+    assert (o[0] == first[0]).all()                                   # env 0: first observation of its new episode
+    assert (r == r0).all() and (o[1:] == o0[1:]).all()                # its reward is that of the finished step
+    assert v.episode_steps.tolist() == [0, 4, 1, 1]
+    o, r, d = v.step_tensor(a)
+    o0, r0, _ = ref.step_tensor(a)
+    assert d.tolist() == [False, True, False, False]
+    assert (o[1] == first[1]).all() and (r[1:] == r0[1:]).all() and (o[2:] == o0[2:]).all()
+    fresh = make_vec(4)                    # env 0 is now one step into a fresh episode
+    fresh.reset_tensor()
+    of, rf, _ = fresh.step_tensor(a)
+    assert (o[0] == of[0]).all() and (r[0] == rf[0]).all()
+    assert (v.get_state()[0] == fresh.get_state()[0]).all()
+
+
 def test_non_finite_env_is_contained():
     """A NaN / Inf state resets that env (done = 1, reward 0) and leaves every other env bitwise untouched."""
     v = make_vec(6)

@@ -398,6 +398,8 @@ int trex_batch_create(const TrexModel *model, int num_envs, int device, TrexBatc
   A(n * sizeof(int32_t), (void **)&b->arr.contact_count);
   A(n * sizeof(float), (void **)&b->arr.normal_impulse);
   A(n * sizeof(int32_t), (void **)&b->arr.pair_perm);
+  A(n * sizeof(int32_t), (void **)&b->arr.episode_steps);
+  b->arr.max_episode_steps = 0;
   size_t nv = model->host.hull_xyz.size();
   A((nv ? nv : 1) * sizeof(float4), (void **)&b->arr.hull);
   const size_t nl = model->host.link_names.size();
@@ -507,6 +509,27 @@ int trex_batch_debug_step(TrexBatch *b, const float *actions_dev, float *obs_dev
   BUF_TRY(debug_dev, 4096 * sizeof(float), "trex_batch_debug_step: debug");   // (diagnostic builds: 4096 + 16 N)
   HIP_TRY(trex_launch_step(b->dmodel, b->arr, b->n, actions_dev, obs_dev, nullptr, nullptr, nullptr, b->wd, b->we, b->wk,
                            debug_dev, (hipStream_t)stream, nullptr, 3 * b->nj, 1));
+  return TREX_OK;
+}
+
+int trex_batch_set_episode_limit(TrexBatch *b, int max_episode_steps, const int32_t *episode_steps_dev, void *stream) {
+  if (check_batch(b)) return TREX_E_INVALID;
+  if (max_episode_steps < 0) return fail(TREX_E_INVALID, "max_episode_steps must be >= 0 (0 = no limit)");
+  DeviceGuard guard(b->device);
+  BUF_TRY(episode_steps_dev, (size_t)b->n * sizeof(int32_t), "trex_batch_set_episode_limit: episode_steps");
+  b->arr.max_episode_steps = max_episode_steps;
+  if (episode_steps_dev)
+    HIP_TRY(hipMemcpyAsync(b->arr.episode_steps, episode_steps_dev, (size_t)b->n * sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  else
+    HIP_TRY(hipMemsetAsync(b->arr.episode_steps, 0, (size_t)b->n * sizeof(int32_t), (hipStream_t)stream));
+  return TREX_OK;
+}
+int trex_batch_get_episode_steps(TrexBatch *b, int32_t *episode_steps_dev, void *stream) {
+  if (check_batch(b)) return TREX_E_INVALID;
+  if (!episode_steps_dev) return fail(TREX_E_INVALID, "episode_steps is null");
+  DeviceGuard guard(b->device);
+  BUF_TRY(episode_steps_dev, (size_t)b->n * sizeof(int32_t), "trex_batch_get_episode_steps: episode_steps");
+  HIP_TRY(hipMemcpyAsync(episode_steps_dev, b->arr.episode_steps, (size_t)b->n * sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return TREX_OK;
 }
 

@@ -52,7 +52,10 @@ struct TrexBatchArrays {
   uint8_t *motors_on;
   int32_t *contact_count;
   float *normal_impulse;
-  int32_t *pair_perm;     /* [N] wave slot -> env id: envs sorted by last contact count, lightest paired with heaviest */
+  int32_t *pair_perm;     /* [N] wave slot -> env id: envs ranked by their last contact count (wave balance) */
+  int32_t *episode_steps; /* [N] env-steps since the env's last reset (the harness's episode limit) */
+  int32_t max_episode_steps;  /* 0 = no limit; > 0: an env whose count reaches it is reset INSIDE the step launch */
+  int32_t pad_;
   float4 *hull;  /* [nv] body-frame collision points: xyz + support radius (0 for hull vertices) */
   int num_links;
   const int *link_body;   /* [L] body of each URDF link */

@@ -341,6 +341,18 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
   bool do_reset = false;
   bool bad;
   if (RESET) do_reset = args.reset_mask ? (args.reset_mask[env] != 0) : true;
+  if (RESET && !do_reset) {
+    // an env that is not reset only hands out its observation again: no physics, no kinematics, no LDS. (The
+    // episode-limit reset of a VecEnv runs with a mask every step: about N/1000 envs reset, the rest end here.)
+    if (args.obs && tid >= 1 && tid < nb) {
+      float *o = args.obs + (size_t)env * args.obs_stride;
+      const int slot = M->obs_slot[tid];
+      o[slot] = args.arr.q[(size_t)env * TL + tid];
+      o[nj + slot] = args.arr.qd[(size_t)env * TL + tid];
+      o[2 * nj + slot] = args.arr.tau[(size_t)env * TL + tid];
+    }
+    return;
+  }
   {
     const bool is_body = tid < nb, is_joint = tid >= 1 && tid < nb;
     float q = 0.f, qd = 0.f, mtau = 0.f, target = 0.f;
@@ -454,8 +466,74 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
 #if TREX_STAMPS
   unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
 #endif
+  // Episode limit of the harness (the reference never terminates, trex_env.py:183-184; a VecEnv auto-resets): the env
+  // whose count reaches the limit with this step finishes the step - reward, done = 1 - and then, IN THE SAME LAUNCH,
+  // goes to the start pose and takes the reset's un-actuated settle substep, so that its observation is the first
+  // one of the new episode (baselines' VecEnv semantics) and no separate reset launch sits between two steps.
+  int age = 0;
+  bool time_up = false;
+  if (!RESET && args.arr.max_episode_steps > 0) {
+    age = args.arr.episode_steps[env] + 1;
+    time_up = age >= args.arr.max_episode_steps;
+  }
+  const int n_total = n_sub + ((!RESET && time_up) ? 1 : 0);
+  bool env_bad = false;
+  float lift = 0.f, drift = 0.f, energy = 0.f;
+  // the end of an env-step: head position (needs FK at the new pose: getLinkState(computeForwardKinematics=1)), reward
+  // terms, failure containment
+  auto finish_step = [&]() {
+    const int lt = lane_id();
+    const int bl = lt & (TL - 1);
+    const bool is_body = lt < nb, is_joint = lt >= 1 && lt < nb;
+    float head[3];
+    {
+      const int parent = is_body ? M->parent[bl] : 0;
+      const int psrc = parent < 0 ? 0 : parent;
+      const int depth = is_body ? M->depth[bl] : -1;
+      float R[9], r[3], dpar[3], Sa[3];
+      forward_kinematics(lt, psrc, depth, R, r, dpar, Sa);
+      const float hp[3] = {M->head_point[0], M->head_point[1], M->head_point[2]};
+      float o[3];
+      matvec3(R, hp, o);
+      const int hb = M->head_body;
+#pragma unroll
+      for (int k = 0; k < 3; k++) head[k] = rl(pos[k] + r[k] + o[k], hb);
+    }
+    float q = W.st[ST_Q][bl], qd = W.st[ST_QD][bl], mtau = W.st[ST_TAU][bl];
+    if (lt >= TL) { q = 0.f; qd = 0.f; mtau = 0.f; }
+    const float power = wsum(is_joint ? fabsf(qd * mtau) : 0.f);
+    lift = args.w_distance * (2.5f - head[2]) * (2.5f - head[2]);
+    drift = args.w_drift * (head[0] * head[0] + head[1] * head[1]);
+    energy = args.w_energy * power;
+    // failure containment (no reference counterpart): an env whose state stopped being finite is put
+    // back on the start pose with zero velocities and reports done = 1 once, with a finite reward of 0 (one env
+    // per wave: no other env can be affected).
+    bool badl = !(fabsf(q) < 3.0e38f) || !(fabsf(qd) < 3.0e38f);
+#pragma unroll
+    for (int k = 0; k < 3; k++) badl |= !(fabsf(pos[k]) < 3.0e38f) || !(fabsf(bv[k]) < 3.0e38f) || !(fabsf(bw[k]) < 3.0e38f);
+#pragma unroll
+    for (int k = 0; k < 4; k++) badl |= !(fabsf(quat[k]) < 3.0e38f);
+    env_bad = bad || (__ballot(badl) != 0ull);
+  };
+  auto to_start_pose = [&]() {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { pos[k] = uni(M->base_pos0[k]); bv[k] = 0.f; bw[k] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) quat[k] = uni(M->base_quat0[k]);
+    const int l = lane_id();   // (not tid: an address formed from it would be kept - and spilled - from the prologue on)
+    if (l < TL) {
+      W.st[ST_Q][l] = l < nb ? Mo()->q_start[l] : 0.f;
+      W.st[ST_QD][l] = 0.f; W.st[ST_TAU][l] = 0.f;
+    }
+    __syncthreads();
+  };
 #pragma unroll 1
-  for (int sub = 0; sub < n_sub; sub++) {
+  for (int sub = 0; sub < n_total; sub++) {
+    if (!RESET && sub == n_sub) {   // time is up: the step is complete, the new episode starts (settle substep follows)
+      finish_step();
+      to_start_pose();
+      motors_on = false;            // remove_joint_control, trex_robot.py:309
+    }
     // lane id and what derives from it are RE-derived at the start of every phase (RELANE): a value that
     // lived from the top of the substep would be spilled across the phases in between
     int lt, bl;                        // bl: index into the [32]-wide model / state rows (lanes >= 32 alias, never used)
@@ -1615,47 +1693,14 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
 #undef REROW
   }
 
-  // ---- epilogue: head position (needs FK at the new pose: getLinkState(computeForwardKinematics=1)), reward
+  // ---- epilogue
+  if (RESET || !time_up) finish_step();
+  if (env_bad && !time_up) to_start_pose();     // (a time-limit reset already left a sound state)
   const int lt = lane_id();
   const int bl = lt & (TL - 1);
-  const bool is_body = lt < nb, is_joint = lt >= 1 && lt < nb;
-  float head[3];
-  {
-    const int parent = is_body ? M->parent[bl] : 0;
-    const int psrc = parent < 0 ? 0 : parent;
-    const int depth = is_body ? M->depth[bl] : -1;
-    float R[9], r[3], dpar[3], Sa[3];
-    forward_kinematics(lt, psrc, depth, R, r, dpar, Sa);
-    const float hp[3] = {M->head_point[0], M->head_point[1], M->head_point[2]};
-    float o[3];
-    matvec3(R, hp, o);
-    const int hb = M->head_body;
-#pragma unroll
-    for (int k = 0; k < 3; k++) head[k] = rl(pos[k] + r[k] + o[k], hb);
-  }
+  const bool is_joint = lt >= 1 && lt < nb;
   float q = W.st[ST_Q][bl], qd = W.st[ST_QD][bl], mtau = W.st[ST_TAU][bl];
   if (lt >= TL) { q = 0.f; qd = 0.f; mtau = 0.f; }
-  const float power = wsum(is_joint ? fabsf(qd * mtau) : 0.f);
-  const float lift = args.w_distance * (2.5f - head[2]) * (2.5f - head[2]);
-  const float drift = args.w_drift * (head[0] * head[0] + head[1] * head[1]);
-  const float energy = args.w_energy * power;
-
-  // ---- failure containment (no reference counterpart): an env whose state stopped being
-  // finite is put back on the start pose with zero velocities and reports done = 1 once, with a finite
-  // reward of 0 (one env per wave: no other env can be affected).
-  bool badl = !(fabsf(q) < 3.0e38f) || !(fabsf(qd) < 3.0e38f);
-#pragma unroll
-  for (int k = 0; k < 3; k++) badl |= !(fabsf(pos[k]) < 3.0e38f) || !(fabsf(bv[k]) < 3.0e38f) || !(fabsf(bw[k]) < 3.0e38f);
-#pragma unroll
-  for (int k = 0; k < 4; k++) badl |= !(fabsf(quat[k]) < 3.0e38f);
-  const bool env_bad = bad || (__ballot(badl) != 0ull);
-  if (env_bad) {
-#pragma unroll
-    for (int k = 0; k < 3; k++) { pos[k] = M->base_pos0[k]; bv[k] = 0.f; bw[k] = 0.f; }
-#pragma unroll
-    for (int k = 0; k < 4; k++) quat[k] = M->base_quat0[k];
-    q = is_body ? M->q_start[bl] : 0.f; qd = 0.f; mtau = 0.f;
-  }
   // ---- write back
   const bool store_state = RESET ? do_reset : true;
   if (store_state) {
@@ -1676,6 +1721,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
       args.arr.motors_on[env] = motors_on ? 1 : 0;
       args.arr.contact_count[env] = stat_nc;
       args.arr.normal_impulse[env] = stat_imp;
+      if (RESET || args.arr.max_episode_steps > 0) args.arr.episode_steps[env] = (RESET || time_up || env_bad) ? 0 : age;
     }
   }
   if (args.obs && is_joint) {
@@ -1685,8 +1731,10 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
   }
   if (lt == 0) {
     if (args.reward) args.reward[(size_t)env * args.scal_stride] = env_bad ? 0.f : -lift - drift - energy;
-    if (args.done) args.done[env] = env_bad ? 1 : 0;  // should_terminate() is constant False, trex_env.py:183-184
-    if (args.done_f) args.done_f[(size_t)env * args.scal_stride] = env_bad ? 1.f : 0.f;
+    // should_terminate() is constant False (trex_env.py:183-184): done only flags the harness's episode limit and
+    // a contained non-finite env
+    if (args.done) args.done[env] = (env_bad || time_up) ? 1 : 0;
+    if (args.done_f) args.done_f[(size_t)env * args.scal_stride] = (env_bad || time_up) ? 1.f : 0.f;
     if (args.penalties) {
       args.penalties[env * 3 + 0] = env_bad ? 0.f : lift; args.penalties[env * 3 + 1] = env_bad ? 0.f : drift;
       args.penalties[env * 3 + 2] = env_bad ? 0.f : energy;

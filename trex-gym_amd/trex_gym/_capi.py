@@ -37,6 +37,7 @@ SYMBOLS = [
     "trex_model_num_links", "trex_model_link_info", "trex_batch_link_transforms",
     "trex_model_use_primitive_collision", "trex_model_fit_hull_primitives",
     "trex_build_id", "trex_batch_step_rows", "trex_batch_reset_rows",
+    "trex_batch_set_episode_limit", "trex_batch_get_episode_steps",
 ]
 
 _vp = C.c_void_p
@@ -66,6 +67,8 @@ lib.trex_batch_reset.argtypes = [_vp, _vp, _vp, _vp]
 lib.trex_batch_step.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp]
 lib.trex_batch_step_rows.argtypes = [_vp, _vp, _vp, C.c_int, _vp, _vp]
 lib.trex_batch_reset_rows.argtypes = [_vp, _vp, _vp, C.c_int, _vp]
+lib.trex_batch_set_episode_limit.argtypes = [_vp, C.c_int, _vp, _vp]
+lib.trex_batch_get_episode_steps.argtypes = [_vp, _vp, _vp]
 lib.trex_batch_debug_step.argtypes = [_vp, _vp, _vp, _vp, _vp]
 lib.trex_batch_get_state.argtypes = [_vp, _vp, _vp]
 lib.trex_batch_set_state.argtypes = [_vp, _vp, _vp]
@@ -265,6 +268,14 @@ class Batch:
         check(lib.trex_batch_reset_rows(self.h, self._p(mask, "uint8", n, "mask"),
                                         self._p(rows, "float32", n * (3 * J + 2), "rows"), int(rows.shape[1]),
                                         self._stream(stream)))
+
+    def set_episode_limit(self, max_episode_steps, episode_steps=None, stream=None):
+        """Episode limit inside the step launch (0 = off); episode_steps [n] int32 sets the per-env counts."""
+        check(lib.trex_batch_set_episode_limit(self.h, int(max_episode_steps), self._p(episode_steps, "int32", self.num_envs, "episode_steps"),
+                                               self._stream(stream)))
+
+    def get_episode_steps(self, out, stream=None):
+        check(lib.trex_batch_get_episode_steps(self.h, self._p(out, "int32", self.num_envs, "episode_steps"), self._stream(stream)))
 
     def debug_step(self, actions, obs, debug, stream=None):
         n, J = self.num_envs, self.J

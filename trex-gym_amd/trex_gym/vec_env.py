@@ -6,7 +6,8 @@ DummyVecEnv([make_env]) -> VecNormalize): num_envs, observation_space, action_sp
 step_async(), step_wait(), step(), close(); plus tensor-native variants that keep everything in HBM
 (step_tensor) for an on-device policy.  Episodes never terminate in the reference
 (should_terminate() is constant False, trex_env.py:183-184); a time limit, if any, is the
-harness's: `max_episode_steps` (None = never) auto-resets like a VecEnv does and reports done=True.
+harness's: `max_episode_steps` (None = never) auto-resets like a VecEnv does and reports done=True -
+inside the step launch itself (trex_batch_set_episode_limit).
 
 Outputs live in ONE row block `rows` [n, 3J+2] f32 = obs | reward | done (written by the kernel in that
 layout: trex_batch_step_rows); `obs`, `rew` and `done_f` are views into it.
@@ -66,8 +67,10 @@ class TrexVecEnv:
         self.rew = self.rows[:, 3 * J]
         self.done_f = self.rows[:, 3 * J + 1]
         self.penalties = torch.zeros(n, 3, device=self.device)
-        self.episode_steps = torch.zeros(n, dtype=torch.int32, device=self.device)
         self.max_episode_steps = max_episode_steps
+        if max_episode_steps is not None:
+            # the step launch itself resets an env whose episode is over (no reset launch between two steps)
+            self.batch.set_episode_limit(int(max_episode_steps))
         self._actions = None
         self._gather_buf = None
         self._pipe = None
@@ -76,11 +79,18 @@ class TrexVecEnv:
     def reset_tensor(self, mask=None):
         """Reset all envs (mask=None) or those with mask != 0 (uint8 [n]). Returns obs [n, 3J]."""
         self.batch.reset_rows(self.rows, mask)
-        if mask is None:
-            self.episode_steps.zero_()
-        else:
-            self.episode_steps.masked_fill_(mask.bool(), 0)
         return self.obs
+
+    @property
+    def episode_steps(self):
+        """[n] int32: env-steps since each env's last reset (kept by the batch when an episode limit is set)."""
+        out = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+        self.batch.get_episode_steps(out)
+        return out
+
+    def set_episode_steps(self, steps):
+        """Set the per-env step counts (e.g. to stagger the episodes of a benchmark)."""
+        self.batch.set_episode_limit(int(self.max_episode_steps or 0), steps.to(device=self.device, dtype=torch.int32).contiguous())
 
     def step_tensor(self, actions):
         """actions [n, J] f32 on device -> (obs [n,3J], reward [n], done [n] bool). Views into buffers
@@ -89,17 +99,10 @@ class TrexVecEnv:
             actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
         if tuple(actions.shape) != (self.num_envs, self.J):
             raise ValueError("actions must have shape (%d, %d), got %s" % (self.num_envs, self.J, tuple(actions.shape)))
+        # (with max_episode_steps the launch also resets the envs whose episode ends with this step: done = 1,
+        # reward of the finished step, observation of the new episode - VecEnv semantics, no second launch)
         self.batch.step_rows(actions, self.rows, self.penalties)
-        done = self.done_f != 0
-        if self.max_episode_steps is not None:
-            # VecEnv auto-reset without a host sync: the masked reset kernel is launched every step
-            # (waves whose mask is 0 skip the physics) and obs becomes that of the new episode.
-            self.episode_steps += 1
-            done = done | (self.episode_steps >= self.max_episode_steps)   # time limit, or a contained non-finite env
-            self.done_f.copy_(done)          # the gathered row block carries the harness's done too
-            self.batch.reset_rows(self.rows, done.to(torch.uint8))
-            self.episode_steps.masked_fill_(done, 0)
-        return self.obs, self.rew, done
+        return self.obs, self.rew, self.done_f != 0
 
     def all_gather_rows(self, rows=None):
         """[global N, 3J+2] = obs | reward | done of EVERY env, on every rank: the one collective of the path
