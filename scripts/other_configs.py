@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""BASELINE configs other than the headline, on one GPU: batch-size sweep (config 4'), domain randomisation (config 5),
+collision primitives, and the on-device PPO loop (config 3). Writes a markdown table.
+    python scripts/other_configs.py <out.md>"""
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+os.chdir(ROOT)
+out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/other_configs.md"
+
+
+def bench(*extra):
+    cmd = [sys.executable, "bench.py", "--steps", "200", "--warmup", "30", "--no-cpu-baseline"] + list(extra)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if not lines:
+        return None, r.stderr[-400:]
+    return json.loads(lines[-1]), ""
+
+
+rows = ["| config | envs | env-steps/s | ms/step | step launch ms | mean contact points |", "|---|---|---|---|---|---|"]
+cases = [("random actions (4')", n, ["--envs-per-gpu", str(n)]) for n in (256, 1024, 2048, 4096, 8192, 16384, 32768)]
+cases += [("5 domain randomisation", 4096, ["--domain-rand"]), ("collision primitives", 4096, ["--collision", "primitives"])]
+for name, n, extra in cases:
+    d, err = bench(*extra)
+    if d is None:
+        rows.append("| %s | %d | FAILED %s | | | |" % (name, n, err.replace("\n", " ")))
+        continue
+    rows.append("| %s | %d | %.3f M | %.4f | %.4f | %.2f |" % (name, n, d["value"] / 1e6, d["ms_per_step"], d["roofline"]["kernel_ms"],
+                                                             d["state_mix"]["mean_contacts"]))
+    print(rows[-1], flush=True)
+
+# config 3: PPO-driven, learner included
+code = r'''
+import sys, time, torch
+sys.path.insert(0, "trex-gym_amd")
+from trex_gym.trex_train import build_environment
+from trex_gym.ppo import PPO
+for graphs in (False, True):
+    env = build_environment(4096)
+    agent = PPO(env, nsteps=32, nminibatches=32, noptepochs=4, seed=0, use_graphs=graphs)
+    for _ in range(3):
+        agent.update(agent.collect())
+    torch.cuda.synchronize(); t0 = time.perf_counter(); s0 = agent.total_env_steps
+    tr = 0.0
+    for _ in range(10):
+        t1 = time.perf_counter(); b = agent.collect(); torch.cuda.synchronize(); tr += time.perf_counter() - t1
+        agent.update(b)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print("PPO graphs=%d %.0f %.0f" % (graphs, (agent.total_env_steps - s0) / dt, (agent.total_env_steps - s0) / tr), flush=True)
+'''
+r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+rows += ["", "PPO-driven (config 3; 4096 envs, nsteps 32, 4 epochs x 32 minibatches, policy + learner on the same GPU):", ""]
+for l in r.stdout.splitlines():
+    if l.startswith("PPO"):
+        _, g, total, roll = l.split()
+        rows.append("* %s: %.0f k env-steps/s including the learner; rollout alone (policy + env step + normalisation) %.0f k env-steps/s"
+                    % ("HIP-graph replay" if g.endswith("1") else "eager", float(total) / 1e3, float(roll) / 1e3))
+if r.returncode:
+    rows.append("PPO run failed: " + r.stderr[-400:].replace("\n", " "))
+open(out, "w").write("\n".join(rows) + "\n")
+print("\n".join(rows))
