@@ -31,7 +31,7 @@ for name, n, extra in cases:
         rows.append("| %s | %d | FAILED %s | | | |" % (name, n, err.replace("\n", " ")))
         continue
     rows.append("| %s | %d | %.3f M | %.4f | %.4f | %.2f |" % (name, n, d["value"] / 1e6, d["ms_per_step"], d["roofline"]["kernel_ms"],
-                                                             d["state_mix"]["mean_contacts"]))
+                                                             d["state_mix"]["mean_contacts"][-1]))
     print(rows[-1], flush=True)
 
 # config 3: PPO-driven, learner included

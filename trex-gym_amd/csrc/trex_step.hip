@@ -1347,7 +1347,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
     // reaches the other rows as ONE v_readlane (SGPR broadcast) + ONE fma per lane. y (not z = lam + y) is
     // what is accumulated: it is small where lam is large, and the rounding of a row's own update stays in y.
     // Row order (the oracle's): limit rows (ascending joint), motor rows, then per point normal, friction x, y.
-    float lam = 0.f, lim_lam = 0.f;
+    float lam = 0.f, lam_lo = 0.f, lim_lam = 0.f;
 #if TREX_PRIO_MODE == 1 || TREX_PRIO_MODE == 3
     set_priority(nc);
 #endif
@@ -1398,199 +1398,160 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
           const float sd = rl(dl, j);
           y += W.u.jcol[j - 1][lt] * sd;
         }
-        // motor rows (joints beyond nb are null rows: y = 0, bounds 0), hand-placed: 7 issue slots per row instead of
-        // the compiler's 8. The impulse change d_j, which sits in an SGPR for the broadcast anyway, is captured into
-        // lane j of `dvec` with v_writelane (1 VALU instead of v_cmp + v_cndmask) and the 25 impulses are committed
-        // after the block, lam += dvec. The v_writelane of row j-1 is the wait state between v_sub and the v_readlane
-        // of its result; s_nop 1 covers the two wait states between v_readlane and the v_fmac that reads the SGPR.
-        // (A speculative UNCLAMPED block - d_j = y_j, 4 slots per row, committed only if no bound was crossed - does
-        // not pay: under random actions 7 percent of the motor rows sit at 3e5 N m and the block then runs twice.)
+        // motor rows (joints beyond nb are null rows: y = 0, bounds 0), hand-placed: 5 issue slots per row (the compiler's
+        // form of TREX_ROW takes 8). With the bounds SHIFTED by the impulse, d_j = clamp(lam_j + y_j) - lam_j =
+        // med3(y_j, lo - lam_j, hi - lam_j) is one instruction; a motor row is visited once per sweep, so the shifted
+        // bounds are formed for all lanes at once before the block. d_j, which sits in an SGPR for the broadcast anyway,
+        // is captured into lane j of `dvec` with v_writelane and the 25 impulses are committed after the block,
+        // lam += dvec - as a two-sum, the rounding error kept in lam_lo: the sum of the d's that the other rows have
+        // seen and the stored impulse must not drift apart over 60 sweeps (an unsaturated row adds y itself, not
+        // fl(lam + y) - lam). The v_writelane of row j-1 is the wait state between v_med3 and the v_readlane of its
+        // result; s_nop 1 covers the two wait states between v_readlane and the v_fmac that reads the SGPR.
+        // (Not taken: accumulating z = lam + y instead of y saves the add too but costs 30x the one-step error of an
+        // airborne env - z is as large as a saturated impulse, y is small; a speculative UNCLAMPED block - d_j = y_j,
+        // committed only if no bound was crossed - runs twice too often: under random actions 7 percent of the motor
+        // rows sit at 3e5 N m.)
         {
           static_assert(NJMAX == 25, "the blocks below are written out for 25 motor rows");
           int dvec = 0, sa_, sb_;
-          float t_, d_;
-          asm volatile("v_add_f32_e32 %2, %6, %0\n\t"
-                       "v_med3_f32 %2, %2, -%7, %7\n\t"
-                       "v_sub_f32_e32 %3, %2, %6\n\t"
+          float d_;
+          const float blo = (-mhi - lam) - lam_lo, bhi = (mhi - lam) - lam_lo;
+          asm volatile("v_med3_f32 %2, %0, %5, %6\n\t"
                        "s_nop 0\n\t"
-                       "v_readlane_b32 %4, %3, 1\n\t"
+                       "v_readlane_b32 %3, %2, 1\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_e32 %0, %3, %7\n\t"
+                       "v_med3_f32 %2, %0, %5, %6\n\t"
+                       "v_writelane_b32 %1, %3, 1\n\t"
+                       "v_readlane_b32 %4, %2, 2\n\t"
                        "s_nop 1\n\t"
                        "v_fmac_f32_e32 %0, %4, %8\n\t"
-                       "v_add_f32_e32 %2, %6, %0\n\t"
-                       "v_med3_f32 %2, %2, -%7, %7\n\t"
-                       "v_sub_f32_e32 %3, %2, %6\n\t"
-                       "v_writelane_b32 %1, %4, 1\n\t"
-                       "v_readlane_b32 %5, %3, 2\n\t"
+                       "v_med3_f32 %2, %0, %5, %6\n\t"
+                       "v_writelane_b32 %1, %4, 2\n\t"
+                       "v_readlane_b32 %3, %2, 3\n\t"
                        "s_nop 1\n\t"
-                       "v_fmac_f32_e32 %0, %5, %9\n\t"
-                       "v_add_f32_e32 %2, %6, %0\n\t"
-                       "v_med3_f32 %2, %2, -%7, %7\n\t"
-                       "v_sub_f32_e32 %3, %2, %6\n\t"
-                       "v_writelane_b32 %1, %5, 2\n\t"
-                       "v_readlane_b32 %4, %3, 3\n\t"
+                       "v_fmac_f32_e32 %0, %3, %9\n\t"
+                       "v_med3_f32 %2, %0, %5, %6\n\t"
+                       "v_writelane_b32 %1, %3, 3\n\t"
+                       "v_readlane_b32 %4, %2, 4\n\t"
                        "s_nop 1\n\t"
                        "v_fmac_f32_e32 %0, %4, %10\n\t"
-                       "v_add_f32_e32 %2, %6, %0\n\t"
-                       "v_med3_f32 %2, %2, -%7, %7\n\t"
-                       "v_sub_f32_e32 %3, %2, %6\n\t"
-                       "v_writelane_b32 %1, %4, 3\n\t"
-                       "v_readlane_b32 %5, %3, 4\n\t"
+                       "v_med3_f32 %2, %0, %5, %6\n\t"
+                       "v_writelane_b32 %1, %4, 4\n\t"
+                       "v_readlane_b32 %3, %2, 5\n\t"
                        "s_nop 1\n\t"
-                       "v_fmac_f32_e32 %0, %5, %11\n\t"
-                       "v_add_f32_e32 %2, %6, %0\n\t"
-                       "v_med3_f32 %2, %2, -%7, %7\n\t"
-                       "v_sub_f32_e32 %3, %2, %6\n\t"
-                       "v_writelane_b32 %1, %5, 4\n\t"
-                       "v_readlane_b32 %4, %3, 5\n\t"
+                       "v_fmac_f32_e32 %0, %3, %11\n\t"
+                       "v_med3_f32 %2, %0, %5, %6\n\t"
+                       "v_writelane_b32 %1, %3, 5\n\t"
+                       "v_readlane_b32 %4, %2, 6\n\t"
                        "s_nop 1\n\t"
                        "v_fmac_f32_e32 %0, %4, %12\n\t"
-                       "v_add_f32_e32 %2, %6, %0\n\t"
-                       "v_med3_f32 %2, %2, -%7, %7\n\t"
-                       "v_sub_f32_e32 %3, %2, %6\n\t"
-                       "v_writelane_b32 %1, %4, 5\n\t"
-                       "v_readlane_b32 %5, %3, 6\n\t"
+                       "v_med3_f32 %2, %0, %5, %6\n\t"
+                       "v_writelane_b32 %1, %4, 6\n\t"
+                       "v_readlane_b32 %3, %2, 7\n\t"
                        "s_nop 1\n\t"
-                       "v_fmac_f32_e32 %0, %5, %13\n\t"
-                       "v_add_f32_e32 %2, %6, %0\n\t"
-                       "v_med3_f32 %2, %2, -%7, %7\n\t"
-                       "v_sub_f32_e32 %3, %2, %6\n\t"
-                       "v_writelane_b32 %1, %5, 6\n\t"
-                       "v_readlane_b32 %4, %3, 7\n\t"
+                       "v_fmac_f32_e32 %0, %3, %13\n\t"
+                       "v_med3_f32 %2, %0, %5, %6\n\t"
+                       "v_writelane_b32 %1, %3, 7\n\t"
+                       "v_readlane_b32 %4, %2, 8\n\t"
                        "s_nop 1\n\t"
                        "v_fmac_f32_e32 %0, %4, %14\n\t"
-                       "v_add_f32_e32 %2, %6, %0\n\t"
-                       "v_med3_f32 %2, %2, -%7, %7\n\t"
-                       "v_sub_f32_e32 %3, %2, %6\n\t"
-                       "v_writelane_b32 %1, %4, 7\n\t"
-                       "v_readlane_b32 %5, %3, 8\n\t"
+                       "v_med3_f32 %2, %0, %5, %6\n\t"
+                       "v_writelane_b32 %1, %4, 8\n\t"
+                       "v_readlane_b32 %3, %2, 9\n\t"
                        "s_nop 1\n\t"
-                       "v_fmac_f32_e32 %0, %5, %15\n\t"
-                       "v_add_f32_e32 %2, %6, %0\n\t"
-                       "v_med3_f32 %2, %2, -%7, %7\n\t"
-                       "v_sub_f32_e32 %3, %2, %6\n\t"
-                       "v_writelane_b32 %1, %5, 8\n\t"
-                       "v_readlane_b32 %4, %3, 9\n\t"
+                       "v_fmac_f32_e32 %0, %3, %15\n\t"
+                       "v_med3_f32 %2, %0, %5, %6\n\t"
+                       "v_writelane_b32 %1, %3, 9\n\t"
+                       "v_readlane_b32 %4, %2, 10\n\t"
                        "s_nop 1\n\t"
                        "v_fmac_f32_e32 %0, %4, %16\n\t"
-                       "v_add_f32_e32 %2, %6, %0\n\t"
-                       "v_med3_f32 %2, %2, -%7, %7\n\t"
-                       "v_sub_f32_e32 %3, %2, %6\n\t"
-                       "v_writelane_b32 %1, %4, 9\n\t"
-                       "v_readlane_b32 %5, %3, 10\n\t"
+                       "v_med3_f32 %2, %0, %5, %6\n\t"
+                       "v_writelane_b32 %1, %4, 10\n\t"
+                       "v_readlane_b32 %3, %2, 11\n\t"
                        "s_nop 1\n\t"
-                       "v_fmac_f32_e32 %0, %5, %17\n\t"
-                       "v_add_f32_e32 %2, %6, %0\n\t"
-                       "v_med3_f32 %2, %2, -%7, %7\n\t"
-                       "v_sub_f32_e32 %3, %2, %6\n\t"
-                       "v_writelane_b32 %1, %5, 10\n\t"
-                       "v_readlane_b32 %4, %3, 11\n\t"
+                       "v_fmac_f32_e32 %0, %3, %17\n\t"
+                       "v_med3_f32 %2, %0, %5, %6\n\t"
+                       "v_writelane_b32 %1, %3, 11\n\t"
+                       "v_readlane_b32 %4, %2, 12\n\t"
                        "s_nop 1\n\t"
                        "v_fmac_f32_e32 %0, %4, %18\n\t"
-                       "v_add_f32_e32 %2, %6, %0\n\t"
-                       "v_med3_f32 %2, %2, -%7, %7\n\t"
-                       "v_sub_f32_e32 %3, %2, %6\n\t"
-                       "v_writelane_b32 %1, %4, 11\n\t"
-                       "v_readlane_b32 %5, %3, 12\n\t"
+                       "v_med3_f32 %2, %0, %5, %6\n\t"
+                       "v_writelane_b32 %1, %4, 12\n\t"
+                       "v_readlane_b32 %3, %2, 13\n\t"
                        "s_nop 1\n\t"
-                       "v_fmac_f32_e32 %0, %5, %19\n\t"
-                       "v_add_f32_e32 %2, %6, %0\n\t"
-                       "v_med3_f32 %2, %2, -%7, %7\n\t"
-                       "v_sub_f32_e32 %3, %2, %6\n\t"
-                       "v_writelane_b32 %1, %5, 12\n\t"
-                       "v_readlane_b32 %4, %3, 13\n\t"
-                       "s_nop 1\n\t"
-                       "v_fmac_f32_e32 %0, %4, %20\n\t"
-                       "v_writelane_b32 %1, %4, 13\n\t"
-                       : "+v"(y), "+v"(dvec), "=&v"(t_), "=&v"(d_), "=&s"(sa_), "=&s"(sb_)
-                       : "v"(lam), "v"(mhi), "v"(Bm[0]), "v"(Bm[1]), "v"(Bm[2]), "v"(Bm[3]), "v"(Bm[4]), "v"(Bm[5]), "v"(Bm[6]), "v"(Bm[7]), "v"(Bm[8]), "v"(Bm[9]), "v"(Bm[10]), "v"(Bm[11]), "v"(Bm[12]));
-          asm volatile("v_add_f32_e32 %2, %6, %0\n\t"
-                       "v_med3_f32 %2, %2, -%7, %7\n\t"
-                       "v_sub_f32_e32 %3, %2, %6\n\t"
+                       "v_fmac_f32_e32 %0, %3, %19\n\t"
+                       "v_writelane_b32 %1, %3, 13\n\t"
+                       : "+v"(y), "+v"(dvec), "=&v"(d_), "=&s"(sa_), "=&s"(sb_)
+                       : "v"(blo), "v"(bhi), "v"(Bm[0]), "v"(Bm[1]), "v"(Bm[2]), "v"(Bm[3]), "v"(Bm[4]), "v"(Bm[5]), "v"(Bm[6]), "v"(Bm[7]), "v"(Bm[8]), "v"(Bm[9]), "v"(Bm[10]), "v"(Bm[11]), "v"(Bm[12]));
+          asm volatile("v_med3_f32 %2, %0, %5, %6\n\t"
                        "s_nop 0\n\t"
-                       "v_readlane_b32 %5, %3, 14\n\t"
+                       "v_readlane_b32 %4, %2, 14\n\t"
                        "s_nop 1\n\t"
-                       "v_fmac_f32_e32 %0, %5, %8\n\t"
-                       "v_add_f32_e32 %2, %6, %0\n\t"
-                       "v_med3_f32 %2, %2, -%7, %7\n\t"
-                       "v_sub_f32_e32 %3, %2, %6\n\t"
-                       "v_writelane_b32 %1, %5, 14\n\t"
-                       "v_readlane_b32 %4, %3, 15\n\t"
+                       "v_fmac_f32_e32 %0, %4, %7\n\t"
+                       "v_med3_f32 %2, %0, %5, %6\n\t"
+                       "v_writelane_b32 %1, %4, 14\n\t"
+                       "v_readlane_b32 %3, %2, 15\n\t"
+                       "s_nop 1\n\t"
+                       "v_fmac_f32_e32 %0, %3, %8\n\t"
+                       "v_med3_f32 %2, %0, %5, %6\n\t"
+                       "v_writelane_b32 %1, %3, 15\n\t"
+                       "v_readlane_b32 %4, %2, 16\n\t"
                        "s_nop 1\n\t"
                        "v_fmac_f32_e32 %0, %4, %9\n\t"
-                       "v_add_f32_e32 %2, %6, %0\n\t"
-                       "v_med3_f32 %2, %2, -%7, %7\n\t"
-                       "v_sub_f32_e32 %3, %2, %6\n\t"
-                       "v_writelane_b32 %1, %4, 15\n\t"
-                       "v_readlane_b32 %5, %3, 16\n\t"
+                       "v_med3_f32 %2, %0, %5, %6\n\t"
+                       "v_writelane_b32 %1, %4, 16\n\t"
+                       "v_readlane_b32 %3, %2, 17\n\t"
                        "s_nop 1\n\t"
-                       "v_fmac_f32_e32 %0, %5, %10\n\t"
-                       "v_add_f32_e32 %2, %6, %0\n\t"
-                       "v_med3_f32 %2, %2, -%7, %7\n\t"
-                       "v_sub_f32_e32 %3, %2, %6\n\t"
-                       "v_writelane_b32 %1, %5, 16\n\t"
-                       "v_readlane_b32 %4, %3, 17\n\t"
+                       "v_fmac_f32_e32 %0, %3, %10\n\t"
+                       "v_med3_f32 %2, %0, %5, %6\n\t"
+                       "v_writelane_b32 %1, %3, 17\n\t"
+                       "v_readlane_b32 %4, %2, 18\n\t"
                        "s_nop 1\n\t"
                        "v_fmac_f32_e32 %0, %4, %11\n\t"
-                       "v_add_f32_e32 %2, %6, %0\n\t"
-                       "v_med3_f32 %2, %2, -%7, %7\n\t"
-                       "v_sub_f32_e32 %3, %2, %6\n\t"
-                       "v_writelane_b32 %1, %4, 17\n\t"
-                       "v_readlane_b32 %5, %3, 18\n\t"
+                       "v_med3_f32 %2, %0, %5, %6\n\t"
+                       "v_writelane_b32 %1, %4, 18\n\t"
+                       "v_readlane_b32 %3, %2, 19\n\t"
                        "s_nop 1\n\t"
-                       "v_fmac_f32_e32 %0, %5, %12\n\t"
-                       "v_add_f32_e32 %2, %6, %0\n\t"
-                       "v_med3_f32 %2, %2, -%7, %7\n\t"
-                       "v_sub_f32_e32 %3, %2, %6\n\t"
-                       "v_writelane_b32 %1, %5, 18\n\t"
-                       "v_readlane_b32 %4, %3, 19\n\t"
+                       "v_fmac_f32_e32 %0, %3, %12\n\t"
+                       "v_med3_f32 %2, %0, %5, %6\n\t"
+                       "v_writelane_b32 %1, %3, 19\n\t"
+                       "v_readlane_b32 %4, %2, 20\n\t"
                        "s_nop 1\n\t"
                        "v_fmac_f32_e32 %0, %4, %13\n\t"
-                       "v_add_f32_e32 %2, %6, %0\n\t"
-                       "v_med3_f32 %2, %2, -%7, %7\n\t"
-                       "v_sub_f32_e32 %3, %2, %6\n\t"
-                       "v_writelane_b32 %1, %4, 19\n\t"
-                       "v_readlane_b32 %5, %3, 20\n\t"
+                       "v_med3_f32 %2, %0, %5, %6\n\t"
+                       "v_writelane_b32 %1, %4, 20\n\t"
+                       "v_readlane_b32 %3, %2, 21\n\t"
                        "s_nop 1\n\t"
-                       "v_fmac_f32_e32 %0, %5, %14\n\t"
-                       "v_add_f32_e32 %2, %6, %0\n\t"
-                       "v_med3_f32 %2, %2, -%7, %7\n\t"
-                       "v_sub_f32_e32 %3, %2, %6\n\t"
-                       "v_writelane_b32 %1, %5, 20\n\t"
-                       "v_readlane_b32 %4, %3, 21\n\t"
+                       "v_fmac_f32_e32 %0, %3, %14\n\t"
+                       "v_med3_f32 %2, %0, %5, %6\n\t"
+                       "v_writelane_b32 %1, %3, 21\n\t"
+                       "v_readlane_b32 %4, %2, 22\n\t"
                        "s_nop 1\n\t"
                        "v_fmac_f32_e32 %0, %4, %15\n\t"
-                       "v_add_f32_e32 %2, %6, %0\n\t"
-                       "v_med3_f32 %2, %2, -%7, %7\n\t"
-                       "v_sub_f32_e32 %3, %2, %6\n\t"
-                       "v_writelane_b32 %1, %4, 21\n\t"
-                       "v_readlane_b32 %5, %3, 22\n\t"
+                       "v_med3_f32 %2, %0, %5, %6\n\t"
+                       "v_writelane_b32 %1, %4, 22\n\t"
+                       "v_readlane_b32 %3, %2, 23\n\t"
                        "s_nop 1\n\t"
-                       "v_fmac_f32_e32 %0, %5, %16\n\t"
-                       "v_add_f32_e32 %2, %6, %0\n\t"
-                       "v_med3_f32 %2, %2, -%7, %7\n\t"
-                       "v_sub_f32_e32 %3, %2, %6\n\t"
-                       "v_writelane_b32 %1, %5, 22\n\t"
-                       "v_readlane_b32 %4, %3, 23\n\t"
+                       "v_fmac_f32_e32 %0, %3, %16\n\t"
+                       "v_med3_f32 %2, %0, %5, %6\n\t"
+                       "v_writelane_b32 %1, %3, 23\n\t"
+                       "v_readlane_b32 %4, %2, 24\n\t"
                        "s_nop 1\n\t"
                        "v_fmac_f32_e32 %0, %4, %17\n\t"
-                       "v_add_f32_e32 %2, %6, %0\n\t"
-                       "v_med3_f32 %2, %2, -%7, %7\n\t"
-                       "v_sub_f32_e32 %3, %2, %6\n\t"
-                       "v_writelane_b32 %1, %4, 23\n\t"
-                       "v_readlane_b32 %5, %3, 24\n\t"
+                       "v_med3_f32 %2, %0, %5, %6\n\t"
+                       "v_writelane_b32 %1, %4, 24\n\t"
+                       "v_readlane_b32 %3, %2, 25\n\t"
                        "s_nop 1\n\t"
-                       "v_fmac_f32_e32 %0, %5, %18\n\t"
-                       "v_add_f32_e32 %2, %6, %0\n\t"
-                       "v_med3_f32 %2, %2, -%7, %7\n\t"
-                       "v_sub_f32_e32 %3, %2, %6\n\t"
-                       "v_writelane_b32 %1, %5, 24\n\t"
-                       "v_readlane_b32 %4, %3, 25\n\t"
-                       "s_nop 1\n\t"
-                       "v_fmac_f32_e32 %0, %4, %19\n\t"
-                       "v_writelane_b32 %1, %4, 25\n\t"
-                       : "+v"(y), "+v"(dvec), "=&v"(t_), "=&v"(d_), "=&s"(sa_), "=&s"(sb_)
-                       : "v"(lam), "v"(mhi), "v"(Bm[13]), "v"(Bm[14]), "v"(Bm[15]), "v"(Bm[16]), "v"(Bm[17]), "v"(Bm[18]), "v"(Bm[19]), "v"(Bm[20]), "v"(Bm[21]), "v"(Bm[22]), "v"(Bm[23]), "v"(Bm[24]));
-          lam += __int_as_float(dvec);
+                       "v_fmac_f32_e32 %0, %3, %18\n\t"
+                       "v_writelane_b32 %1, %3, 25\n\t"
+                       : "+v"(y), "+v"(dvec), "=&v"(d_), "=&s"(sa_), "=&s"(sb_)
+                       : "v"(blo), "v"(bhi), "v"(Bm[13]), "v"(Bm[14]), "v"(Bm[15]), "v"(Bm[16]), "v"(Bm[17]), "v"(Bm[18]), "v"(Bm[19]), "v"(Bm[20]), "v"(Bm[21]), "v"(Bm[22]), "v"(Bm[23]), "v"(Bm[24]));
+          {   // lam += dvec, the rounding error of the sum kept in lam_lo (two-sum: no assumption on magnitudes)
+            const float dv_ = __int_as_float(dvec), sum_ = lam + dv_, bb_ = sum_ - lam;
+            lam_lo += (lam - (sum_ - bb_)) + (dv_ - bb_);
+            lam = sum_;
+          }
         }
         // the live point slots, in order (dead slots have no bit in `alive`)
         unsigned long long alive = nrm_mask != 0ull ? alive_points() : 0ull;   // (an airborne env has no point rows at all)
@@ -1601,6 +1562,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
       }
 #undef TREX_ROW
 #undef TREX_POINT
+      lam += lam_lo;
     }
 #if TREX_PRIO_MODE == 1 || TREX_PRIO_MODE == 3
     __builtin_amdgcn_s_setprio(0);

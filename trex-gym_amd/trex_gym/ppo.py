@@ -135,6 +135,13 @@ class PPO:
         T, n = self.nsteps, self.env.num_envs
         if self.use_graphs:
             if self._rollout_graph is None:
+                # the GEMM library sets itself up on the first call of a shape, which a capturing stream refuses:
+                # one policy evaluation outside the capture (no env step, no state change)
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    self.policy.dist(self.obs); self.policy.value(self.obs)
+                torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
                 self._rollout_graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._rollout_graph):
