@@ -49,6 +49,12 @@
 #ifndef TREX_STAMPS
 #define TREX_STAMPS 0
 #endif
+#ifndef TREX_PRIO_HEAVY
+#define TREX_PRIO_HEAVY 9
+#endif
+#ifndef TREX_PRIO_HEAVY_LEVEL
+#define TREX_PRIO_HEAVY_LEVEL 3
+#endif
 #ifndef TREX_PRIO_MODE
 #define TREX_PRIO_MODE 1   // 0 none, 1 by contact count during the sweeps only, 2 for the whole substep
 #endif
@@ -261,6 +267,7 @@ __device__ __forceinline__ void chol6_solve(const Chol6 &c, const float *r, floa
 constexpr int NJMAX = 25;                // hinge joints at most (26 bodies)
 constexpr int NROW = NJMAX + 3 * MAXC;   // constraint rows of one env: 25 motor rows + 13 x (normal, 2 friction) = 64
 static_assert(NROW == 64, "one constraint row per lane");
+#define KROW_LANE(k) ((k) < 3 * MAXC - 1 ? NJMAX + 1 + (k) : 0)
 constexpr int CLANE0 = NJMAX + 1;        // contact row k lives on lane CLANE0 + k (k < 38) and on lane 0 (k = 38)
 // Body record, parked after the tree phases and read by the row walks (float4 reads, 80-byte stride:
 // 16 lanes reading 16 different records hit 16 different bank quartets):
@@ -411,6 +418,9 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
   };
 #if TREX_PRIO_MODE == 2
   if (!RESET) set_priority(uni(args.arr.contact_count[env]));
+#endif
+#if TREX_PRIO_MODE == 4
+  if (!RESET && uni(args.arr.contact_count[env]) >= TREX_PRIO_HEAVY) __builtin_amdgcn_s_setprio(TREX_PRIO_HEAVY_LEVEL);
 #endif
 
   const float floor_z = M->prm[TP_FLOOR_Z], margin = M->prm[TP_CONTACT_MARGIN];
@@ -1348,7 +1358,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
     // what is accumulated: it is small where lam is large, and the rounding of a row's own update stays in y.
     // Row order (the oracle's): limit rows (ascending joint), motor rows, then per point normal, friction x, y.
     float lam = 0.f, lam_lo = 0.f, lim_lam = 0.f;
-#if TREX_PRIO_MODE == 1 || TREX_PRIO_MODE == 3
+#if TREX_PRIO_MODE == 1 || TREX_PRIO_MODE == 3 || TREX_PRIO_MODE == 4
     set_priority(nc);
 #endif
     {
@@ -1367,17 +1377,49 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
 // blocks: a dead point costs a scalar bit test, and the test is repeated after every point that was processed
 // (it changed y). Bitwise the same result as visiting every row: the skipped updates would add B * 0.
 #define TREX_POINT(S)                                                                                  \
-  if (alive & (1ull << krow_lane(3 * (S)))) {                                                          \
-    const float nl_ = fmaxf(lam + y, 0.f);                                                             \
-    const float d_ = nl_ - lam;                                                                        \
-    const float sd_ = rl(d_, krow_lane(3 * (S)));                                                      \
-    const float hi_ = mu * rl(nl_, krow_lane(3 * (S)));                                                \
-    if (vs == krow_lane(3 * (S))) lam = nl_;                                                           \
-    y = __builtin_fmaf(Bc[3 * (S)], sd_, y);                                                           \
-    TREX_ROW(krow_lane(3 * (S) + 1), Bc[3 * (S) + 1], -hi_, hi_)                                       \
-    TREX_ROW(krow_lane(3 * (S) + 2), Bc[3 * (S) + 2], -hi_, hi_)                                       \
-    alive = alive_points();                                                                            \
-  }
+  asm volatile("s_bitcmp1_b64 %[al], %[ln]\n\t"                                                       \
+               "s_cbranch_scc0 1f\n\t"                                                                 \
+               /* normal row: nl = max(lam + y, 0) */                                                  \
+               "v_add_f32_e32 %[t], %[lam], %[y]\n\t"                                                  \
+               "v_max_f32_e32 %[t], 0, %[t]\n\t"                                                       \
+               "v_sub_f32_e32 %[d], %[t], %[lam]\n\t"                                                  \
+               "v_readlane_b32 %[snl], %[t], %[ln]\n\t"                                                \
+               "v_readlane_b32 %[sd], %[d], %[ln]\n\t"                                                 \
+               "v_cmp_eq_u32_e32 vcc, %[ln], %[vs]\n\t"                                                \
+               "v_mul_f32_e32 %[hi], %[snl], %[mu]\n\t"                                                \
+               "v_fmac_f32_e32 %[y], %[sd], %[b0]\n\t"                                                 \
+               "v_cndmask_b32_e32 %[lam], %[lam], %[t], vcc\n\t"                                       \
+               /* friction x: nl = med3(lam + y, -hi, hi) */                                           \
+               "v_cmp_eq_u32_e32 vcc, %[lx], %[vs]\n\t"                                                \
+               "v_add_f32_e32 %[t], %[lam], %[y]\n\t"                                                  \
+               "v_med3_f32 %[t], %[t], -%[hi], %[hi]\n\t"                                              \
+               "v_sub_f32_e32 %[d], %[t], %[lam]\n\t"                                                  \
+               "v_cndmask_b32_e32 %[lam], %[lam], %[t], vcc\n\t"                                       \
+               "v_readlane_b32 %[sd], %[d], %[lx]\n\t"                                                 \
+               "v_cmp_eq_u32_e32 vcc, %[ly], %[vs]\n\t"                                                \
+               "s_nop 0\n\t"                                                                           \
+               "v_fmac_f32_e32 %[y], %[sd], %[b1]\n\t"                                                 \
+               /* friction y */                                                                        \
+               "v_add_f32_e32 %[t], %[lam], %[y]\n\t"                                                  \
+               "v_med3_f32 %[t], %[t], -%[hi], %[hi]\n\t"                                              \
+               "v_sub_f32_e32 %[d], %[t], %[lam]\n\t"                                                  \
+               "v_cndmask_b32_e32 %[lam], %[lam], %[t], vcc\n\t"                                       \
+               "v_readlane_b32 %[sd], %[d], %[ly]\n\t"                                                 \
+               "v_cmp_neq_f32_e64 %[tmp], 0, %[lam]\n\t"                                               \
+               "s_nop 0\n\t"                                                                           \
+               "v_fmac_f32_e32 %[y], %[sd], %[b2]\n\t"                                                 \
+               /* which points can change anything now */                                              \
+               "v_add_f32_e32 %[t], %[lam], %[y]\n\t"                                                  \
+               "v_cmp_lt_f32_e32 vcc, 0, %[t]\n\t"                                                     \
+               "s_or_b64 %[al], vcc, %[tmp]\n\t"                                                       \
+               "s_and_b64 %[al], %[al], %[nrm]\n\t"                                                    \
+               "1:\n\t"                                                                                \
+               : [y] "+v"(y), [lam] "+v"(lam), [al] "+s"(alive), [t] "=&v"(pt_), [d] "=&v"(pd_), [hi] "=&v"(ph_), \
+                 [snl] "=&s"(psn_), [sd] "=&s"(psd_), [tmp] "=&s"(ptm_)                                \
+               : [vs] "v"(vs), [mu] "v"(mu), [b0] "v"(Bc[3 * (S)]), [b1] "v"(Bc[3 * (S) + 1]), [b2] "v"(Bc[3 * (S) + 2]), \
+                 [nrm] "s"(nrm_mask), [ln] "n"(KROW_LANE(3 * (S))), [lx] "n"(KROW_LANE(3 * (S) + 1)),      \
+                 [ly] "n"(KROW_LANE(3 * (S) + 2))                                                      \
+               : "vcc", "scc");
       // lanes that hold the normal row of a live point slot
       const unsigned long long nrm_mask = __ballot(lt >= CLANE0 && (lt - CLANE0) % 3 == 0 && (lt - CLANE0) / 3 >= s0);
       auto alive_points = [&]() { return nrm_mask & __ballot(lam != 0.f || lam + y > 0.f); };
@@ -1556,8 +1598,12 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
         // the live point slots, in order (dead slots have no bit in `alive`)
         unsigned long long alive = nrm_mask != 0ull ? alive_points() : 0ull;   // (an airborne env has no point rows at all)
         if (alive != 0ull) {
-          TREX_POINT(0) TREX_POINT(1) TREX_POINT(2) TREX_POINT(3) TREX_POINT(4) TREX_POINT(5) TREX_POINT(6)
-          TREX_POINT(7) TREX_POINT(8) TREX_POINT(9) TREX_POINT(10) TREX_POINT(11) TREX_POINT(12)
+          float pt_, pd_, ph_;
+          int psn_, psd_;
+          unsigned long long ptm_;
+          if (s0 < 7) { TREX_POINT(0) TREX_POINT(1) TREX_POINT(2) TREX_POINT(3) TREX_POINT(4) TREX_POINT(5) TREX_POINT(6) }
+          if (s0 < 10) { TREX_POINT(7) TREX_POINT(8) TREX_POINT(9) }
+          TREX_POINT(10) TREX_POINT(11) TREX_POINT(12)
         }
       }
 #undef TREX_ROW
@@ -1566,6 +1612,9 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
     }
 #if TREX_PRIO_MODE == 1 || TREX_PRIO_MODE == 3
     __builtin_amdgcn_s_setprio(0);
+#endif
+#if TREX_PRIO_MODE == 4
+    if (nc >= TREX_PRIO_HEAVY) __builtin_amdgcn_s_setprio(TREX_PRIO_HEAVY_LEVEL); else __builtin_amdgcn_s_setprio(0);
 #endif
     STAMP(7);
     RELANE();
