@@ -133,6 +133,40 @@ __device__ __forceinline__ int wmini(int v) {   // non-negative values
   r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
   return min((int)r[0], (int)r[1]);
 }
+// all-reduce inside aligned lane GROUPS of G = 8, 16, 32 or 64 lanes (G wave-uniform): the first DPP steps of the
+// wave reductions above
+__device__ __forceinline__ float gmaxf(float v, int G) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  if (G >= 16) v = fmaxf(v, dpp_mov<0x140>(v));
+  if (G >= 32) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  }
+  if (G >= 64) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  }
+  return v;
+}
+__device__ __forceinline__ int gmini(int v, int G) {
+  v = min(v, dpp_mov_i<0xB1>(v));
+  v = min(v, dpp_mov_i<0x4E>(v));
+  v = min(v, dpp_mov_i<0x141>(v));
+  if (G >= 16) v = min(v, dpp_mov_i<0x140>(v));
+  if (G >= 32) {
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    v = min((int)r[0], (int)r[1]);
+  }
+  if (G >= 64) {
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    v = min((int)r[0], (int)r[1]);
+  }
+  return v;
+}
 // wave arg-max with ties to the lowest index: returns the winning (score, index) on every lane
 __device__ __forceinline__ void wargmax(float &score, int &index) {
   const float best = -wminf(-score);
@@ -288,11 +322,11 @@ struct WaveLds {
 enum { ST_Q, ST_QD, ST_TAU, ST_TARGET, ST_NQD, ST_MDG };
 static_assert(sizeof(WaveLds) <= 10240, "16 workgroups per CU need <= 10 KB of LDS each");
 // Contact generation works in the union area (the inertia slots are written after it):
-constexpr int CG_WORDS = 28;             // in-margin mask words per body: hulls of up to 896 vertices (pelvis: 840)
+constexpr int CG_WORDS = 32;             // in-margin mask words per body: bit j of word w <-> vertex 32 j + w of the body (up to 1024)
 struct CgLds {
   unsigned long long best[TL];           // per body: min of (ordered distance << 32 | vertex)                256 B
   float4 ent[TL][2];                     // near-hull table: end position | vertex - position | body | body v0 ; Rz, zb  1024 B
-  unsigned cm[TL][CG_WORDS];             // per body: bit i <-> vertex hull_start[body] + i inside the margin   3584 B
+  unsigned cm[TL][CG_WORDS];             // per body: word w, bit j <-> vertex hull_start[body] + 32 j + w inside the margin   4096 B
 };
 static_assert(sizeof(CgLds) <= sizeof(WaveLds::u), "contact-generation scratch fits the union area");
 
@@ -512,9 +546,10 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
     float q = W.st[ST_Q][bl], qd = W.st[ST_QD][bl], mtau = W.st[ST_TAU][bl];
     if (lt >= TL) { q = 0.f; qd = 0.f; mtau = 0.f; }
     const float power = wsum(is_joint ? fabsf(qd * mtau) : 0.f);
-    lift = args.w_distance * (2.5f - head[2]) * (2.5f - head[2]);
-    drift = args.w_drift * (head[0] * head[0] + head[1] * head[1]);
-    energy = args.w_energy * power;
+    // (wave-uniform: kept on the scalar side across the rest of the substep loop)
+    lift = uni(args.w_distance * (2.5f - head[2]) * (2.5f - head[2]));
+    drift = uni(args.w_drift * (head[0] * head[0] + head[1] * head[1]));
+    energy = uni(args.w_energy * power);
     // failure containment (no reference counterpart): an env whose state stopped being finite is put
     // back on the start pose with zero velocities and reports done = 1 once, with a finite reward of 0 (one env
     // per wave: no other env can be affected).
@@ -675,7 +710,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
             // only the height decides; h.w = support radius (0 for a hull vertex): the sphere's lowest point
             const float dd = q[u].w + (q[u].x * h[u].x + q[u].y * h[u].y + q[u].z * h[u].z) - h[u].w;
             if (vtx[u] >= 0 && dd < margin) {
-              if (rel[u] < 32 * CG_WORDS) atomicOr(&G.cm[bod[u]][rel[u] >> 5], 1u << (rel[u] & 31));
+              if (rel[u] < 32 * CG_WORDS) atomicOr(&G.cm[bod[u]][rel[u] & 31], 1u << (rel[u] >> 5));
               unsigned ub = __float_as_uint(dd);
               ub ^= (ub >> 31) ? 0xffffffffu : 0x80000000u;    // order-preserving map of the float to unsigned
               atomicMin(&G.best[bod[u]], ((unsigned long long)ub << 32) | (unsigned)vtx[u]);
@@ -702,7 +737,6 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
         }
         active_mask = (unsigned)__ballot(a_v >= 0);
       }
-      constexpr int SMALL_HULL = 96;
       int n_active = __popc(active_mask);
       int K = n_active > 0 ? maxc / n_active : 0;
       K = K > 4 ? 4 : (K < 1 ? 1 : K);
@@ -728,106 +762,123 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
         }
         nc = n_active;
       } else {
-        for (unsigned am = active_mask; am != 0u; am &= am - 1u) {
-          const int b = __ffs(am) - 1;
-          int sel[4] = {-1, -1, -1, -1};
-          float px[4][3], pd[4];
-          sel[0] = rl(a_v, b);
+        // ---- K >= 2 points per body, at most 6 touching bodies: the bodies are processed SIDE BY SIDE, one aligned
+        // lane group each (64, 32, 16 or 8 lanes); lane g of a group owns the body's vertices g, g + GS, ... and finds
+        // them in the mask words g, g + GS, ... (< 32). Every pass ends in group-wide DPP reductions: max of the
+        // score, ties to the lowest vertex index (as the oracle's scan order gives), then the winner's position.
+        const int GS = n_active <= 1 ? 64 : (n_active <= 2 ? 32 : (n_active <= 4 ? 16 : 8));
+        const int g = lt & (GS - 1), gi = lt / GS;
+        int b = 0;
+        bool act = false;
+        {
+          int i = 0;
+          for (unsigned am = active_mask; am != 0u; am &= am - 1u, i++)
+            if (gi == i) { b = __ffs(am) - 1; act = true; }
+        }
+        float Rb[9], rb[3], px[4][3];
+        int sel[3] = {-1, -1, -1};
 #pragma unroll
-          for (int c = 0; c < 3; c++) px[0][c] = rl(a_x[c], b);
-          pd[0] = rl(a_d, b);
-          int nsel = 1;
-          float Rb[9], rb[3];
+        for (int c = 0; c < 9; c++) Rb[c] = wshfl(R[c], b);
 #pragma unroll
-          for (int c = 0; c < 9; c++) Rb[c] = rl(R[c], b);
+        for (int c = 0; c < 3; c++) { rb[c] = wshfl(r[c], b); px[0][c] = wshfl(a_x[c], b); }
+        sel[0] = act ? wshfl(a_v, b) : -1;
+        const int v0 = wshfl(hull_v0, b), v1 = wshfl(hull_v1, b);
+        const bool masked = (v1 - v0) <= 32 * CG_WORDS;
+        // this lane's candidate words (masked bodies); a body beyond the mask capacity is swept
+        unsigned m0 = 0u, m1 = 0u, m2 = 0u, m3 = 0u;
+        if (act && masked) {
+          const unsigned *cw = G.cm[b];
+          if (GS >= 64) m0 = cw[g & 31] & ((g >> 5) ? 0xAAAAAAAAu : 0x55555555u);
+          else if (GS >= 32) m0 = cw[g];
+          else if (GS >= 16) { m0 = cw[g]; m1 = cw[g + 16]; }
+          else { m0 = cw[g]; m1 = cw[g + 8]; m2 = cw[g + 16]; m3 = cw[g + 24]; }
+        }
+        const int wstep = GS >= 32 ? 0 : GS;
+        int nsel = act ? 1 : 0;
+        bool stop = !act;
 #pragma unroll
-          for (int c = 0; c < 3; c++) rb[c] = rl(r[c], b);
-          const int v0 = rl(hull_v0, b), v1 = rl(hull_v1, b);
-          // this lane's candidates of body b: bit i <-> vertex v0 + lane + 64 i (in the margin during pass A)
-          unsigned im = 0u;
-          const bool masked = (v1 - v0) <= 32 * CG_WORDS;
-          if (masked) {
-            const int nw2 = ((v1 - v0) + 63) >> 6;     // vertices per lane
-            for (int i = 0; i < nw2; i++) im |= ((G.cm[b][2 * i + (lt >> 5)] >> (lt & 31)) & 1u) << i;
-          } else {
-            im = 0xffffffffu;   // a hull beyond the mask capacity: sweep it
+        for (int pass = 1; pass < 4; pass++) {
+          if (pass >= K || __ballot(!stop) == 0ull) break;
+          float bs = -3.0e38f;
+          int bi = 0x7fffffff;
+          float ex = 0.f, ey = 0.f, flip = 1.f;
+          if (pass >= 2) { ex = px[1][0] - px[0][0]; ey = px[1][1] - px[0][1]; }
+          if (pass == 3) {
+            const float c3 = ex * (px[2][1] - px[0][1]) - ey * (px[2][0] - px[0][0]);
+            flip = c3 > 0.f ? -1.f : 1.f;
           }
-          {
-            const int o = sel[0] - v0;     // the deepest vertex is taken
-            if (lt == (o & 63) && (o >> 6) < 32) im &= ~(1u << (o >> 6));
-          }
-          bool stop = false;
-#pragma unroll
-          for (int pass = 1; pass < 4; pass++) {
-            if (stop) break;
-            float bs = -3.0e38f;
-            int bi = 0x7fffffff;
-            float ex = 0.f, ey = 0.f, flip = 1.f;
-            if (pass >= 2) { ex = px[1][0] - px[0][0]; ey = px[1][1] - px[0][1]; }
-            if (pass == 3) {
-              const float c3 = ex * (px[2][1] - px[0][1]) - ey * (px[2][0] - px[0][0]);
-              flip = c3 > 0.f ? -1.f : 1.f;
+          float bx[3] = {0.f, 0.f, 0.f};
+          auto visit = [&](int v, const float4 h) {
+            const float hv[3] = {h.x, h.y, h.z};
+            float w[3];
+            matvec3(Rb, hv, w);
+            const float x0 = rb[0] + w[0], x1 = rb[1] + w[1], x2 = rb[2] + w[2] - h.w;
+            const float dd = pos[2] + x2 - floor_z;
+            if (!(dd < margin)) return;
+            if (v == sel[0] || v == sel[1] || v == sel[2]) return;
+            const float dx = x0 - px[0][0], dy = x1 - px[0][1];
+            float score;
+            if (pass == 1) score = dx * dx + dy * dy;
+            else {
+              const float cr = ex * dy - ey * dx;
+              score = (pass == 2) ? fabsf(cr) : flip * cr;
             }
-            float bx[3] = {0.f, 0.f, 0.f};
-            const int nit = (v1 - v0 - lt + 63) / 64;   // strided vertices of this lane
-            auto visit = [&](int v, const float4 h) {
-              const float hv[3] = {h.x, h.y, h.z};
-              float w[3];
-              matvec3(Rb, hv, w);
-              const float x0 = rb[0] + w[0], x1 = rb[1] + w[1], x2 = rb[2] + w[2] - h.w;
-              const float dd = pos[2] + x2 - floor_z;
-              if (!(dd < margin)) return;
-              if (v == sel[0] || v == sel[1] || v == sel[2]) return;
-              const float dx = x0 - px[0][0], dy = x1 - px[0][1];
-              float score;
-              if (pass == 1) score = dx * dx + dy * dy;
-              else {
-                const float cr = ex * dy - ey * dx;
-                score = (pass == 2) ? fabsf(cr) : flip * cr;
+            if (score > bs || (score == bs && v < bi)) { bs = score; bi = v; bx[0] = x0; bx[1] = x1; bx[2] = x2; }
+          };
+          if (__ballot(act && !masked) == 0ull) {
+            unsigned c0 = stop ? 0u : m0, c1 = stop ? 0u : m1, c2 = stop ? 0u : m2, c3 = stop ? 0u : m3;
+            int wb = g & 31;
+            constexpr int UC = 2;   // candidates per trip: their loads are issued together
+            while (__ballot((c0 | c1 | c2 | c3) != 0u) != 0ull) {
+              int vi[UC];
+              float4 hc[UC];
+#pragma unroll
+              for (int u = 0; u < UC; u++) {
+                if (c0 == 0u) { c0 = c1; c1 = c2; c2 = c3; c3 = 0u; wb += wstep; }   // next word of this lane
+                const int j = c0 != 0u ? (__ffs(c0) - 1) : -1;
+                c0 &= c0 - 1u;            // (0 stays 0)
+                vi[u] = j >= 0 ? v0 + 32 * j + wb : -1;
+                hc[u] = args.arr.hull[vi[u] >= 0 ? vi[u] : v0];
               }
-              if (score > bs) { bs = score; bi = v; bx[0] = x0; bx[1] = x1; bx[2] = x2; }
-            };
-            if (masked) {
-              constexpr int UC = 2;   // candidates per trip: their loads are issued together
-              for (unsigned m = im; __ballot(m != 0u) != 0ull;) {
-                int vi[UC];
-                float4 hc[UC];
 #pragma unroll
-                for (int u = 0; u < UC; u++) {
-                  const int i = m != 0u ? (__ffs(m) - 1) : 32;
-                  m &= m - 1u;            // (0 stays 0)
-                  vi[u] = i < nit ? v0 + lt + 64 * i : -1;
-                  hc[u] = args.arr.hull[vi[u] >= 0 ? vi[u] : v0];
-                }
-#pragma unroll
-                for (int u = 0; u < UC; u++)
-                  if (vi[u] >= 0) visit(vi[u], hc[u]);
-              }
-            } else {
-              for (int v = v0 + lt; v < v1; v += 64) visit(v, args.arr.hull[v]);
+              for (int u = 0; u < UC; u++)
+                if (vi[u] >= 0) visit(vi[u], hc[u]);
             }
-            const int mine = bi;
-            wargmax(bs, bi);
-            if (pass >= K || bi == 0x7fffffff || !(bs > 0.f)) stop = true;
-            if (!stop) {
-              const int win = __ffsll((unsigned long long)__ballot(mine == bi)) - 1;   // the lane that holds the winner
-              sel[pass] = bi;
-              px[pass][0] = rl(bx[0], win); px[pass][1] = rl(bx[1], win); px[pass][2] = rl(bx[2], win);
-              pd[pass] = pos[2] + px[pass][2] - floor_z;
-              nsel = pass + 1;
-            }
+          } else if (!stop) {
+            for (int v = v0 + g; v < v1; v += GS) visit(v, args.arr.hull[v]);
           }
+          const int mine = bi;
+          const float best = gmaxf(bs, GS);
+          bi = gmini(bs == best ? bi : 0x7fffffff, GS);
+          if (bi == 0x7fffffff || !(best > 0.f)) stop = true;
+          const bool own = !stop && mine == bi;   // exactly one lane of the group
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            const float wx = gmaxf(own ? bx[c] : -3.0e38f, GS);
+            if (!stop) px[pass][c] = wx;
+          }
+          if (!stop) {
+            if (pass < 3) sel[pass] = bi;
+            nsel = pass + 1;
+          }
+        }
+        // the points go out in body order (= group order), the deepest vertex of a body first
+        int off = 0;
+        for (int i = 0; i < n_active; i++) {
+          const int ni = rl(nsel, i * GS);
+          if (gi > i) off += ni;
+          nc += ni;
+        }
+        if (act && g == 0) {
 #pragma unroll
           for (int k = 0; k < 4; k++) {
-            if (k < nsel && nc < maxc) {
-              if (lt == 0) {
-                float *o = W.cpt[nc];
-                o[0] = __int_as_float(b); o[1] = px[k][0]; o[2] = px[k][1]; o[3] = px[k][2]; o[4] = pd[k];
-              }
-              nc++;
+            if (k < nsel && off + k < maxc) {
+              float *o = W.cpt[off + k];
+              o[0] = __int_as_float(b); o[1] = px[k][0]; o[2] = px[k][1]; o[3] = px[k][2]; o[4] = pos[2] + px[k][2] - floor_z;
             }
           }
         }
+        nc = nc < maxc ? nc : maxc;
       }
     }
     nc = uni(nc);
@@ -1300,7 +1351,9 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
       return -inv0 * a0_;
     };
     auto chain_mask = [&](float4 d0, float *m) {   // u of this row on the levels it shares with the column's chain
-      const unsigned lowdiff = (unsigned)(__ffs((int)(ca0 ^ __float_as_uint(d0.x))) - 1);   // 0xffffffff: identical chains
+      // lowest differing bit of the two packed chains (30 bits); bit 30 is set so that identical chains give 30
+      // without a special case: every level then counts as shared
+      const unsigned lowdiff = (unsigned)__builtin_ctz((ca0 ^ __float_as_uint(d0.x)) | 0x40000000u);
 #pragma unroll
       for (int d = 0; d < MAXD; d++) m[d] = (lowdiff >= 5u * (d + 1)) ? u0[d] : 0.f;
     };
