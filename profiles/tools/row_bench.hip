@@ -17,6 +17,9 @@ __global__ __launch_bounds__(64) void k(float *out, long long *cyc, int sweeps, 
 #pragma unroll
   for (int j = 0; j < NR; j++) B[j] = (tid == j + 1) ? -1.f : 1e-3f * (float)((tid * 7 + j * 13) % 11 - 5);
   float y = 0.01f * (tid + 1), lam = 0.f, blo = -hi, bhi = hi;
+  int dv = 0, sprev = 0, scur = 0;
+  float bsub = 1e-3f * (float)(tid % 5 - 2);
+  float scratchv = 0.f;
   const long long t0 = __builtin_amdgcn_s_memtime();
 #pragma unroll 1
   for (int it = 0; it < sweeps; it++) {
@@ -64,6 +67,51 @@ __global__ __launch_bounds__(64) void k(float *out, long long *cyc, int sweeps, 
         const float sd = rl(d, L);
         y = __builtin_fmaf(B[j], sd, y);
         lam += (vs == L) ? d : 0.f;
+      } else if (VARIANT >= 8 && VARIANT <= 12) {
+        // hand-placed rows of the round-2 kernel: bounds shifted by the impulse, d = med3(y, blo, bhi); the impulse
+        // changes are captured in `dv` (lane L) by v_writelane and committed after the sweep
+        //  8: the kernel's row        med3, writelane, readlane, s_nop 1, fmac                 (5 slots)
+        //  9: without the capture     med3, s_nop 0,   readlane, s_nop 1, fmac                 (5 slots, one VALU less)
+        // 10: two s_nop 0 for s_nop 1 med3, writelane, readlane, s_nop 0, s_nop 0, fmac         (6 slots)
+        // 11: VALU fillers            med3, writelane, readlane, v_mov, v_mov, fmac             (6 slots, two VALU more)
+        // 12: the 7-slot row of before: add, med3, sub, writelane, readlane, s_nop 1, fmac
+        float d_;
+        int s_;
+        if (VARIANT == 8)
+          asm volatile("v_med3_f32 %2, %0, %4, %5\n\tv_writelane_b32 %1, %3, %7\n\tv_readlane_b32 %3, %2, %7\n\ts_nop 1\n\tv_fmac_f32_e32 %0, %3, %6"
+                       : "+v"(y), "+v"(dv), "=&v"(d_), "+s"(sprev) : "v"(blo), "v"(bhi), "v"(B[j]), "n"(1 + (j % 63)));
+        else if (VARIANT == 9)
+          asm volatile("v_med3_f32 %2, %0, %4, %5\n\ts_nop 0\n\tv_readlane_b32 %3, %2, %7\n\ts_nop 1\n\tv_fmac_f32_e32 %0, %3, %6"
+                       : "+v"(y), "+v"(dv), "=&v"(d_), "+s"(sprev) : "v"(blo), "v"(bhi), "v"(B[j]), "n"(1 + (j % 63)));
+        else if (VARIANT == 10)
+          asm volatile("v_med3_f32 %2, %0, %4, %5\n\tv_writelane_b32 %1, %3, %7\n\tv_readlane_b32 %3, %2, %7\n\ts_nop 0\n\ts_nop 0\n\tv_fmac_f32_e32 %0, %3, %6"
+                       : "+v"(y), "+v"(dv), "=&v"(d_), "+s"(sprev) : "v"(blo), "v"(bhi), "v"(B[j]), "n"(1 + (j % 63)));
+        else if (VARIANT == 11)
+          asm volatile("v_med3_f32 %2, %0, %4, %5\n\tv_writelane_b32 %1, %3, %7\n\tv_readlane_b32 %3, %2, %7\n\tv_mov_b32 %8, %4\n\tv_mov_b32 %8, %5\n\tv_fmac_f32_e32 %0, %3, %6"
+                       : "+v"(y), "+v"(dv), "=&v"(d_), "+s"(sprev) : "v"(blo), "v"(bhi), "v"(B[j]), "n"(1 + (j % 63)), "v"(scratchv));
+        else
+          asm volatile("v_add_f32_e32 %2, %8, %0\n\tv_med3_f32 %2, %2, %4, %5\n\tv_sub_f32_e32 %2, %2, %8\n\tv_writelane_b32 %1, %3, %7\n\tv_readlane_b32 %3, %2, %7\n\ts_nop 1\n\tv_fmac_f32_e32 %0, %3, %6"
+                       : "+v"(y), "+v"(dv), "=&v"(d_), "+s"(sprev) : "v"(blo), "v"(bhi), "v"(B[j]), "n"(1 + (j % 63)), "v"(lam));
+        (void)s_;
+      } else if (VARIANT == 13 || VARIANT == 14) {
+        // neighbour fast path: the next row's lane gets this row's change by DPP (wave_shr:1, VGPR to VGPR), the other
+        // lanes by the SGPR broadcast ONE ROW LATER (software-pipelined: no s_nop, the readlane round trip is off the
+        // critical path). 13: with the v_writelane capture, 14: without
+        float d_;
+        if (VARIANT == 13)
+          asm volatile("v_med3_f32 %2, %0, %5, %6\n\t"
+                       "v_fmac_f32_e32 %0, %3, %7\n\t"
+                       "v_readlane_b32 %4, %2, %9\n\t"
+                       "v_fmac_f32_dpp %0, %2, %8 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                       "v_writelane_b32 %1, %3, %9"
+                       : "+v"(y), "+v"(dv), "=&v"(d_), "+s"(sprev), "+s"(scur) : "v"(blo), "v"(bhi), "v"(B[j]), "v"(bsub), "n"(1 + (j % 63)));
+        else
+          asm volatile("v_med3_f32 %2, %0, %5, %6\n\t"
+                       "v_fmac_f32_e32 %0, %3, %7\n\t"
+                       "v_readlane_b32 %4, %2, %9\n\t"
+                       "v_fmac_f32_dpp %0, %2, %8 wave_shr:1 row_mask:0xf bank_mask:0xf"
+                       : "+v"(y), "+v"(dv), "=&v"(d_), "+s"(sprev), "+s"(scur) : "v"(blo), "v"(bhi), "v"(B[j]), "v"(bsub), "n"(1 + (j % 63)));
+        { const int t_ = sprev; sprev = scur; scur = t_; }
       } else if (VARIANT == 5) {   // unclamped, lam not tracked (lower bound: readlane + fma)
         const float sd = rl(y, L);
         y = __builtin_fmaf(B[j], sd, y);
@@ -71,7 +119,7 @@ __global__ __launch_bounds__(64) void k(float *out, long long *cyc, int sweeps, 
     }
   }
   const long long t1 = __builtin_amdgcn_s_memtime();
-  out[blockIdx.x * 64 + tid] = y + lam + blo + bhi;
+  out[blockIdx.x * 64 + tid] = y + lam + blo + bhi + __int_as_float(dv) + scratchv;
   if (tid == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
@@ -105,5 +153,12 @@ int main() {
   run<5>("5 unclamped, lam untracked (bound)", out, cyc, sweeps);
   run<6>("6 short chain, shifted bounds kept", out, cyc, sweeps);
   run<7>("7 short chain, bounds from lam", out, cyc, sweeps);
+  run<12>("12 asm, 7 slots (add med3 sub wl rl nop1 fmac)", out, cyc, sweeps);
+  run<8>("8 asm, 5 slots (med3 wl rl nop1 fmac)", out, cyc, sweeps);
+  run<9>("9 asm, 5 slots, s_nop 0 for the writelane", out, cyc, sweeps);
+  run<10>("10 asm, 6 slots, s_nop 0 x2 for s_nop 1", out, cyc, sweeps);
+  run<11>("11 asm, 6 slots, two v_mov for s_nop 1", out, cyc, sweeps);
+  run<13>("13 neighbour DPP fast path, pipelined broadcast", out, cyc, sweeps);
+  run<14>("14 the same without the capture", out, cyc, sweeps);
   return 0;
 }

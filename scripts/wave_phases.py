@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-wave phase cycles of the one-env-per-wave step kernel in the bench.py state mix (DIAGNOSTIC build:
-make -C trex-gym_amd/csrc stamps_w1 / stamps; TREX_LIB selects it). Every wave accumulates s_memtime deltas
+make -C trex-gym_amd/csrc stamps; TREX_LIB selects it; balanced by contact rank like the product launch). Every wave accumulates s_memtime deltas
 per phase over the 5 substeps of ONE launch; the script prints the mean per phase, the same for the slowest
 waves, and wave time against contact count. Shares, not lengths, are meaningful (the stamps fence the
 scheduler and add global read-modify-writes)."""
@@ -40,8 +40,9 @@ def main():
     torch.cuda.synchronize()
     cnt = torch.zeros(n, dtype=torch.int32, device=dev)
     b.contact_stats(cnt, None)
-    c = cnt.cpu().numpy()
-    raw = dbg.cpu().numpy()[4096:4096 + 11 * n].reshape(11, n)
+    raw = dbg.cpu().numpy()[4096:4096 + 12 * n].reshape(12, n)
+    env_of_wave = raw[11].astype(np.int64)          # the launch is balanced like the product's: wave k runs env perm[k]
+    c = cnt.cpu().numpy()[env_of_wave]              # contacts of the env each wave ran
     d = raw[:9].copy()
     sub = raw[9:11]                      # contact generation split: [small-hull scan, large-hull scan]; d[1] = the rest
     d[1] += sub.sum(0)
@@ -63,7 +64,7 @@ def main():
                 lo_, hi_, sel.sum(), tot[sel].mean(), tot[sel].max(), d[7][sel].mean(), d[7][sel].mean() / (300 * rows)))
 
 
-    # (the diagnostic launch is not balanced: workgroup k = env k, and workgroup k shares its SIMD with k +- 1024 ...)
+    # (workgroup k shares its SIMD with k +- 1024 ...)
     if n == 4096:
         order = np.argsort(tot)[::-1][:8]
         print("slowest waves: cycles, contacts | sweeps, contact gen, pass 2, B build | SIMD mates' (cycles, contacts)")

@@ -440,9 +440,9 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
   // its SIMD, which fill the slots its dependency chain leaves empty. (Mode 2, priority for the whole substep,
   // starved the light waves instead: 3.84 M against 4.12 M env-steps/s.)
 #ifndef TREX_PRIO_T1
-#define TREX_PRIO_T1 3
-#define TREX_PRIO_T2 6
-#define TREX_PRIO_T3 10
+#define TREX_PRIO_T1 1
+#define TREX_PRIO_T2 3
+#define TREX_PRIO_T3 6
 #endif
   auto set_priority = [](int contacts) {
     if (contacts >= TREX_PRIO_T3) __builtin_amdgcn_s_setprio(3);
@@ -455,6 +455,9 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
 #endif
 #if TREX_PRIO_MODE == 4
   if (!RESET && uni(args.arr.contact_count[env]) >= TREX_PRIO_HEAVY) __builtin_amdgcn_s_setprio(TREX_PRIO_HEAVY_LEVEL);
+#endif
+#if TREX_PRIO_MODE == 5
+  __builtin_amdgcn_s_setprio(3);
 #endif
 
   const float floor_z = M->prm[TP_FLOOR_Z], margin = M->prm[TP_CONTACT_MARGIN];
@@ -509,6 +512,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
 
 #if TREX_STAMPS
   unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+  if (args.debug && threadIdx.x == 0) args.debug[4096 + 11 * args.n_envs + blockIdx.x] = (float)env;   // the env of this wave
 #endif
   // Episode limit of the harness (the reference never terminates, trex_env.py:183-184; a VecEnv auto-resets): the env
   // whose count reaches the limit with this step finishes the step - reward, done = 1 - and then, IN THE SAME LAUNCH,
@@ -1414,6 +1418,11 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
 #if TREX_PRIO_MODE == 1 || TREX_PRIO_MODE == 3 || TREX_PRIO_MODE == 4
     set_priority(nc);
 #endif
+#if TREX_PRIO_MODE == 5
+    if (nc >= TREX_PRIO_T2) __builtin_amdgcn_s_setprio(2);
+    else if (nc >= TREX_PRIO_T1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+#endif
     {
 #define TREX_ROW(LANE, BCOL, LO, HI)                                                                   \
   {                                                                                                    \
@@ -1668,6 +1677,9 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
 #endif
 #if TREX_PRIO_MODE == 4
     if (nc >= TREX_PRIO_HEAVY) __builtin_amdgcn_s_setprio(TREX_PRIO_HEAVY_LEVEL); else __builtin_amdgcn_s_setprio(0);
+#endif
+#if TREX_PRIO_MODE == 5
+    __builtin_amdgcn_s_setprio(3);
 #endif
     STAMP(7);
     RELANE();
@@ -1970,7 +1982,12 @@ __global__ __launch_bounds__(1024) void trex_balance_kernel(const int32_t *conta
   for (int i = t; i < n; i += 1024) {
     const int c = contact_count[i];
     const int b = c < 0 ? 0 : (c > 15 ? 15 : c);
-    perm[start[b] + atomicAdd(&fill[b], 1)] = i;
+    // rank r (0 = heaviest) -> workgroup: the first 1024 ranks in order, every later block of 1024 REVERSED, so
+    // that SIMD j (workgroups j, 1024 + j, ...) gets the j-th heaviest env together with the j-th LIGHTEST of each
+    // later block - the sums of work per SIMD are level, not only the heaviest env of each
+    const int r = start[b] + atomicAdd(&fill[b], 1);
+    const int q = r >> 10, m = min(1024, n - (q << 10));
+    perm[q == 0 ? r : (q << 10) + (m - 1 - (r & 1023))] = i;
   }
 }
 
@@ -1980,8 +1997,9 @@ extern "C" {
 hipError_t trex_launch_step(const TrexDeviceModel *model, TrexBatchArrays arr, int n, const float *actions,
                             float *obs, float *reward, uint8_t *done, float *penalties, float wd, float we,
                             float wk, float *debug, hipStream_t stream, float *done_f, int obs_stride, int scal_stride) {
-  // diagnostics launches keep env 0 in workgroup 0
-  const int32_t *perm = (debug || n < 2048 || getenv("TREX_NO_BALANCE")) ? nullptr : arr.pair_perm;
+  // diagnostics launches keep env 0 in workgroup 0 (the stamped build is balanced like the product: it reports
+  // the env of every wave)
+  const int32_t *perm = ((debug && !TREX_STAMPS) || n < 2048 || getenv("TREX_NO_BALANCE")) ? nullptr : arr.pair_perm;
   if (perm) hipLaunchKernelGGL(trex_balance_kernel, dim3(1), dim3(1024), 0, stream, arr.contact_count, arr.pair_perm, n);
   KernelArgs a{model, arr, n, actions, obs, reward, done, done_f, obs_stride, scal_stride, penalties, nullptr, perm, wd, we, wk, debug};
 #if TREX_STAMPS   // diagnostic build: the PRODUCT instantiation, stamped (the dump of <false, true> would change its code)
