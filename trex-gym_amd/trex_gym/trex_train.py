@@ -23,11 +23,26 @@ def build_environment(num_envs, device="cuda:0", max_episode_steps=1000):
                       drift_weight=1.0, max_episode_steps=max_episode_steps)
 
 
-def train(env, num_timesteps, seed, nsteps=32, noptepochs=4, save_path=None, log=print, use_graphs=False):
-    agent = PPO(env, nsteps=nsteps, nminibatches=32, noptepochs=noptepochs, lam=0.95, gamma=0.99, lr=3e-4,
-                cliprange=0.2, ent_coef=0.0, seed=seed, use_graphs=use_graphs)
-    log("Number of actions: %d; number of joints: %d; model mass: %.2f; nsteps %d x %d envs; noptepochs %d"
-        % (env.action_space.shape[0], env.model.num_joints, env.model.total_mass(False), nsteps, env.num_envs, noptepochs))
+# Hyper-parameter presets. "reference" is the ppo2.learn call of the reference's script (trex_train.py:47-60):
+# noptepochs 32, nminibatches 32, lam 0.95, gamma 0.99, lr 3e-4, cliprange 0.2, ent_coef 0. Its rollout is
+# nsteps = 4096 samples of ONE env per update; here an update takes nsteps x num_envs samples of the batched env
+# (nsteps 32 by default: 131072 samples at 4096 envs, minibatches of 4096). "throughput" is the same except 4 epochs
+# per update - what the bench-style measurements of config 3 use.
+PRESETS = {
+    "reference": dict(nminibatches=32, noptepochs=32, lam=0.95, gamma=0.99, lr=3e-4, cliprange=0.2, ent_coef=0.0),
+    "throughput": dict(nminibatches=32, noptepochs=4, lam=0.95, gamma=0.99, lr=3e-4, cliprange=0.2, ent_coef=0.0),
+}
+
+
+def train(env, num_timesteps, seed, nsteps=32, noptepochs=None, save_path=None, log=print, use_graphs=False,
+          preset="throughput"):
+    hp = dict(PRESETS[preset])
+    if noptepochs is not None:
+        hp["noptepochs"] = noptepochs
+    agent = PPO(env, nsteps=nsteps, seed=seed, use_graphs=use_graphs, **hp)
+    log("Number of actions: %d; number of joints: %d; model mass: %.2f; nsteps %d x %d envs; preset %s, noptepochs %d"
+        % (env.action_space.shape[0], env.model.num_joints, env.model.total_mass(False), nsteps, env.num_envs, preset,
+           hp["noptepochs"]))
     hist = agent.learn(num_timesteps, log=log)
     if save_path:
         torch.save({"policy": agent.policy.state_dict(), "obs_mean": agent.obs_rms.mean, "obs_var": agent.obs_rms.var},
@@ -42,12 +57,16 @@ def main(argv=None):
     ap.add_argument("--random_seed", type=int, default=0)            # trex_train.py:29
     ap.add_argument("--num_envs", type=int, default=4096)
     ap.add_argument("--nsteps", type=int, default=32)
-    ap.add_argument("--noptepochs", type=int, default=4)
+    ap.add_argument("--preset", choices=sorted(PRESETS), default="reference",
+                    help="reference: the hyper-parameters of the reference's ppo2.learn call (32 epochs per update)")
+    ap.add_argument("--noptepochs", type=int, default=None, help="override the preset's epochs per update")
+    ap.add_argument("--max_episode_steps", type=int, default=1000)
     ap.add_argument("--save", type=str, default=None)
     ap.add_argument("--graphs", action="store_true", help="replay the rollout and the minibatch update as HIP graphs")
     args = ap.parse_args(argv)
-    env = build_environment(args.num_envs)
-    train(env, args.num_timesteps, args.random_seed, args.nsteps, args.noptepochs, args.save, use_graphs=args.graphs)
+    env = build_environment(args.num_envs, max_episode_steps=args.max_episode_steps)
+    train(env, args.num_timesteps, args.random_seed, args.nsteps, args.noptepochs, args.save, use_graphs=args.graphs,
+          preset=args.preset)
 
 
 if __name__ == "__main__":
