@@ -40,11 +40,14 @@ def main():
     if rs:
         rs.sort(key=lambda r: int(r["Start_Timestamp"]))
         rd = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rs][-steps:]
-        lines.append("`trex_step_kernel<true, false>` (masked episode-limit reset of about N/1000 envs per step, outside the "
-                     "HIP-event bracket): timed region avg %.4f ms" % (sum(rd) / len(rd) / 1e6))
+        lines.append("`trex_step_kernel<true, false>` (reset): %d dispatch(es), all before the timed region - the episode limit "
+                     "is applied inside the step launch (trex_batch_set_episode_limit); avg %.4f ms" % (len(rs), sum(rd) / len(rd) / 1e6))
     r0 = t[-1]
     keys = [k for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size") if k in r0]
     lines.append("dispatch: " + ", ".join("%s=%s" % (k, r0[k]) for k in keys))
+    lines.append("(rocprofv3 prints HALF the allocated vector registers on this target: 128 for the round-1 kernel that the code object "
+                 "lists with .vgpr_count 256; this kernel's .vgpr_count is 128 - `make -C trex-gym_amd/csrc resource-usage`: 128 VGPRs, "
+                 "occupancy 4 waves per SIMD, ScratchSize 0)")
     if bench_json and os.path.exists(bench_json):
         b = json.loads(open(bench_json).read().strip().splitlines()[-1])
         lines += ["", "bench.py line of the same run: value %.0f %s, ms_per_step %.3f, roofline.kernel_ms %.3f (HIP events), "

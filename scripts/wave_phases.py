@@ -67,11 +67,19 @@ def main():
     # (workgroup k shares its SIMD with k +- 1024 ...)
     if n == 4096:
         order = np.argsort(tot)[::-1][:8]
-        print("slowest waves: cycles, contacts | sweeps, contact gen, pass 2, B build | SIMD mates' (cycles, contacts)")
+        # joints on a stop after the step (their limit rows were probably active: compiled rows + a column read from LDS)
+        q = obs[:, :25].cpu().numpy()
+        lo_h, hi_h = np.asarray(m.lower)[None, :], np.asarray(m.upper)[None, :]
+        on_stop = ((q <= lo_h + 1e-6) | (q >= hi_h - 1e-6)).sum(1)[env_of_wave]
+        print("slowest waves: cycles, contacts, joints on a stop | sweeps, contact gen, pass 2, B build | SIMD mates' (cycles, contacts, on a stop)")
         for w in order:
             mates = [(w + 1024 * k) % 4096 for k in (1, 2, 3)]
-            print("  %.3g %2d | %.3g %.3g %.3g %.3g | %s" % (tot[w], c[w], d[7][w], d[1][w], d[3][w], d[6][w],
-                  " ".join("(%.3g, %d)" % (tot[m_], c[m_]) for m_ in mates)))
+            print("  %.3g %2d %2d | %.3g %.3g %.3g %.3g | %s" % (tot[w], c[w], on_stop[w], d[7][w], d[1][w], d[3][w], d[6][w],
+                  " ".join("(%.3g, %d, %d)" % (tot[m_], c[m_], on_stop[m_]) for m_ in mates)))
+        for k in range(0, 6):
+            sel = on_stop == k if k < 5 else on_stop >= k
+            if sel.any():
+                print("envs with %s%d joints on a stop: %5d  wave cycles mean %.3g; sweeps mean %.3g" % (">=" if k == 5 else "", k, sel.sum(), tot[sel].mean(), d[7][sel].mean()))
         simd = tot.reshape(4, 1024)
         print("per-SIMD (k mod 1024): sum of its 4 waves' cycles mean %.3g max %.3g; max of its 4 waves mean %.3g max %.3g" % (
             simd.sum(0).mean(), simd.sum(0).max(), simd.max(0).mean(), simd.max(0).max()))

@@ -459,6 +459,9 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
 #if TREX_PRIO_MODE == 5
   __builtin_amdgcn_s_setprio(3);
 #endif
+#if TREX_PRIO_MODE == 7
+  { const int q_ = (int)(blockIdx.x >> 10); if (q_ == 0) __builtin_amdgcn_s_setprio(3); else if (q_ == 1) __builtin_amdgcn_s_setprio(2); else if (q_ == 2) __builtin_amdgcn_s_setprio(1); }
+#endif
 
   const float floor_z = M->prm[TP_FLOOR_Z], margin = M->prm[TP_CONTACT_MARGIN];
   const int iters = M->n_iterations;
@@ -1418,6 +1421,9 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
 #if TREX_PRIO_MODE == 1 || TREX_PRIO_MODE == 3 || TREX_PRIO_MODE == 4
     set_priority(nc);
 #endif
+#if TREX_PRIO_MODE == 6
+    { const int q_ = (int)(blockIdx.x >> 10); if (q_ == 0) __builtin_amdgcn_s_setprio(3); else if (q_ == 1) __builtin_amdgcn_s_setprio(2); else if (q_ == 2) __builtin_amdgcn_s_setprio(1); }
+#endif
 #if TREX_PRIO_MODE == 5
     if (nc >= TREX_PRIO_T2) __builtin_amdgcn_s_setprio(2);
     else if (nc >= TREX_PRIO_T1) __builtin_amdgcn_s_setprio(1);
@@ -1672,7 +1678,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
 #undef TREX_POINT
       lam += lam_lo;
     }
-#if TREX_PRIO_MODE == 1 || TREX_PRIO_MODE == 3
+#if TREX_PRIO_MODE == 1 || TREX_PRIO_MODE == 3 || TREX_PRIO_MODE == 6
     __builtin_amdgcn_s_setprio(0);
 #endif
 #if TREX_PRIO_MODE == 4
