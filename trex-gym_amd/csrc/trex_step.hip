@@ -1417,7 +1417,8 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
     // reaches the other rows as ONE v_readlane (SGPR broadcast) + ONE fma per lane. y (not z = lam + y) is
     // what is accumulated: it is small where lam is large, and the rounding of a row's own update stays in y.
     // Row order (the oracle's): limit rows (ascending joint), motor rows, then per point normal, friction x, y.
-    float lam = 0.f, lam_lo = 0.f, lim_lam = 0.f;
+    float lam = 0.f, lam_c = 0.f, lim_lam = 0.f;
+    int dvec = 0;   // lane j: the impulse change of motor row j in the current sweep (the other lanes stay 0)
 #if TREX_PRIO_MODE == 1 || TREX_PRIO_MODE == 3 || TREX_PRIO_MODE == 4
     set_priority(nc);
 #endif
@@ -1490,7 +1491,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
                : "vcc", "scc");
       // lanes that hold the normal row of a live point slot
       const unsigned long long nrm_mask = __ballot(lt >= CLANE0 && (lt - CLANE0) % 3 == 0 && (lt - CLANE0) / 3 >= s0);
-      auto alive_points = [&]() { return nrm_mask & __ballot(lam != 0.f || lam + y > 0.f); };
+      auto alive_points = [&]() { return nrm_mask & (__ballot(lam != 0.f) | __ballot(lam + y > 0.f)); };   // (two v_cmp + s_or)
 #pragma unroll 1
       for (int it = 0; it < iters; it++) {
         // the lane id, opaque once per sweep: `vs == j` is then one v_cmp where it is used, not a mask hoisted out
@@ -1513,7 +1514,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
         // med3(y_j, lo - lam_j, hi - lam_j) is one instruction; a motor row is visited once per sweep, so the shifted
         // bounds are formed for all lanes at once before the block. d_j, which sits in an SGPR for the broadcast anyway,
         // is captured into lane j of `dvec` with v_writelane and the 25 impulses are committed after the block,
-        // lam += dvec - as a two-sum, the rounding error kept in lam_lo: the sum of the d's that the other rows have
+        // lam += dvec - compensated, the rounding error kept in lam_c: the sum of the d's that the other rows have
         // seen and the stored impulse must not drift apart over 60 sweeps (an unsaturated row adds y itself, not
         // fl(lam + y) - lam). The v_writelane of row j-1 is the wait state between v_med3 and the v_readlane of its
         // result; s_nop 1 covers the two wait states between v_readlane and the v_fmac that reads the SGPR.
@@ -1523,9 +1524,9 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
         // rows sit at 3e5 N m.)
         {
           static_assert(NJMAX == 25, "the blocks below are written out for 25 motor rows");
-          int dvec = 0, sa_, sb_;
+          int sa_, sb_;
           float d_;
-          const float blo = (-mhi - lam) - lam_lo, bhi = (mhi - lam) - lam_lo;
+          const float blo = (-mhi - lam) + lam_c, bhi = (mhi - lam) + lam_c;
           asm volatile("v_med3_f32 %2, %0, %5, %6\n\t"
                        "s_nop 0\n\t"
                        "v_readlane_b32 %3, %2, 1\n\t"
@@ -1591,11 +1592,10 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
                        "v_readlane_b32 %3, %2, 13\n\t"
                        "s_nop 1\n\t"
                        "v_fmac_f32_e32 %0, %3, %19\n\t"
-                       "v_writelane_b32 %1, %3, 13\n\t"
                        : "+v"(y), "+v"(dvec), "=&v"(d_), "=&s"(sa_), "=&s"(sb_)
                        : "v"(blo), "v"(bhi), "v"(Bm[0]), "v"(Bm[1]), "v"(Bm[2]), "v"(Bm[3]), "v"(Bm[4]), "v"(Bm[5]), "v"(Bm[6]), "v"(Bm[7]), "v"(Bm[8]), "v"(Bm[9]), "v"(Bm[10]), "v"(Bm[11]), "v"(Bm[12]));
           asm volatile("v_med3_f32 %2, %0, %5, %6\n\t"
-                       "s_nop 0\n\t"
+                       "v_writelane_b32 %1, %3, 13\n\t"
                        "v_readlane_b32 %4, %2, 14\n\t"
                        "s_nop 1\n\t"
                        "v_fmac_f32_e32 %0, %4, %7\n\t"
@@ -1655,12 +1655,12 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
                        "s_nop 1\n\t"
                        "v_fmac_f32_e32 %0, %3, %18\n\t"
                        "v_writelane_b32 %1, %3, 25\n\t"
-                       : "+v"(y), "+v"(dvec), "=&v"(d_), "=&s"(sa_), "=&s"(sb_)
+                       : "+v"(y), "+v"(dvec), "=&v"(d_), "+s"(sa_), "=&s"(sb_)
                        : "v"(blo), "v"(bhi), "v"(Bm[13]), "v"(Bm[14]), "v"(Bm[15]), "v"(Bm[16]), "v"(Bm[17]), "v"(Bm[18]), "v"(Bm[19]), "v"(Bm[20]), "v"(Bm[21]), "v"(Bm[22]), "v"(Bm[23]), "v"(Bm[24]));
-          {   // lam += dvec, the rounding error of the sum kept in lam_lo (two-sum: no assumption on magnitudes)
-            const float dv_ = __int_as_float(dvec), sum_ = lam + dv_, bb_ = sum_ - lam;
-            lam_lo += (lam - (sum_ - bb_)) + (dv_ - bb_);
-            lam = sum_;
+          {   // lam += dvec, compensated (Kahan): lam - lam_c is the sum of the d's the other rows have seen
+            const float y_ = __int_as_float(dvec) - lam_c, t_ = lam + y_;
+            lam_c = (t_ - lam) - y_;
+            lam = t_;
           }
         }
         // the live point slots, in order (dead slots have no bit in `alive`)
@@ -1676,7 +1676,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
       }
 #undef TREX_ROW
 #undef TREX_POINT
-      lam += lam_lo;
+      lam -= lam_c;
     }
 #if TREX_PRIO_MODE == 1 || TREX_PRIO_MODE == 3 || TREX_PRIO_MODE == 6
     __builtin_amdgcn_s_setprio(0);
