@@ -1445,50 +1445,57 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
 // 2 cm margin, not pressing. ONE vector test over all normal-row lanes (`alive_points`) therefore precedes the point
 // blocks: a dead point costs a scalar bit test, and the test is repeated after every point that was processed
 // (it changed y). Bitwise the same result as visiting every row: the skipped updates would add B * 0.
-#define TREX_POINT(S)                                                                                  \
-  asm volatile("s_bitcmp1_b64 %[al], %[ln]\n\t"                                                       \
-               "s_cbranch_scc0 1f\n\t"                                                                 \
+#define TREX_POINT_TEXT(P)                                                                             \
+               "s_bitcmp1_b64 %[al], %[ln" #P "]\n\t"                                                  \
+               "s_cbranch_scc0 " #P "f\n\t"                                                            \
                /* normal row: nl = max(lam + y, 0) */                                                  \
                "v_add_f32_e32 %[t], %[lam], %[y]\n\t"                                                  \
                "v_max_f32_e32 %[t], 0, %[t]\n\t"                                                       \
                "v_sub_f32_e32 %[d], %[t], %[lam]\n\t"                                                  \
-               "v_readlane_b32 %[snl], %[t], %[ln]\n\t"                                                \
-               "v_readlane_b32 %[sd], %[d], %[ln]\n\t"                                                 \
-               "v_cmp_eq_u32_e32 vcc, %[ln], %[vs]\n\t"                                                \
+               "v_readlane_b32 %[snl], %[t], %[ln" #P "]\n\t"                                          \
+               "v_readlane_b32 %[sd], %[d], %[ln" #P "]\n\t"                                           \
+               "v_cmp_eq_u32_e32 vcc, %[ln" #P "], %[vs]\n\t"                                          \
                "v_mul_f32_e32 %[hi], %[snl], %[mu]\n\t"                                                \
-               "v_fmac_f32_e32 %[y], %[sd], %[b0]\n\t"                                                 \
+               "v_fmac_f32_e32 %[y], %[sd], %[b0" #P "]\n\t"                                           \
                "v_cndmask_b32_e32 %[lam], %[lam], %[t], vcc\n\t"                                       \
                /* friction x: nl = med3(lam + y, -hi, hi) */                                           \
-               "v_cmp_eq_u32_e32 vcc, %[lx], %[vs]\n\t"                                                \
+               "v_cmp_eq_u32_e32 vcc, %[lx" #P "], %[vs]\n\t"                                          \
                "v_add_f32_e32 %[t], %[lam], %[y]\n\t"                                                  \
                "v_med3_f32 %[t], %[t], -%[hi], %[hi]\n\t"                                              \
                "v_sub_f32_e32 %[d], %[t], %[lam]\n\t"                                                  \
                "v_cndmask_b32_e32 %[lam], %[lam], %[t], vcc\n\t"                                       \
-               "v_readlane_b32 %[sd], %[d], %[lx]\n\t"                                                 \
-               "v_cmp_eq_u32_e32 vcc, %[ly], %[vs]\n\t"                                                \
+               "v_readlane_b32 %[sd], %[d], %[lx" #P "]\n\t"                                           \
+               "v_cmp_eq_u32_e32 vcc, %[ly" #P "], %[vs]\n\t"                                          \
                "s_nop 0\n\t"                                                                           \
-               "v_fmac_f32_e32 %[y], %[sd], %[b1]\n\t"                                                 \
+               "v_fmac_f32_e32 %[y], %[sd], %[b1" #P "]\n\t"                                           \
                /* friction y */                                                                        \
                "v_add_f32_e32 %[t], %[lam], %[y]\n\t"                                                  \
                "v_med3_f32 %[t], %[t], -%[hi], %[hi]\n\t"                                              \
                "v_sub_f32_e32 %[d], %[t], %[lam]\n\t"                                                  \
                "v_cndmask_b32_e32 %[lam], %[lam], %[t], vcc\n\t"                                       \
-               "v_readlane_b32 %[sd], %[d], %[ly]\n\t"                                                 \
+               "v_readlane_b32 %[sd], %[d], %[ly" #P "]\n\t"                                           \
                "v_cmp_neq_f32_e64 %[tmp], 0, %[lam]\n\t"                                               \
                "s_nop 0\n\t"                                                                           \
-               "v_fmac_f32_e32 %[y], %[sd], %[b2]\n\t"                                                 \
+               "v_fmac_f32_e32 %[y], %[sd], %[b2" #P "]\n\t"                                           \
                /* which points can change anything now */                                              \
                "v_add_f32_e32 %[t], %[lam], %[y]\n\t"                                                  \
                "v_cmp_lt_f32_e32 vcc, 0, %[t]\n\t"                                                     \
                "s_or_b64 %[al], vcc, %[tmp]\n\t"                                                       \
                "s_and_b64 %[al], %[al], %[nrm]\n\t"                                                    \
-               "1:\n\t"                                                                                \
-               : [y] "+v"(y), [lam] "+v"(lam), [al] "+s"(alive), [t] "=&v"(pt_), [d] "=&v"(pd_), [hi] "=&v"(ph_), \
-                 [snl] "=&s"(psn_), [sd] "=&s"(psd_), [tmp] "=&s"(ptm_)                                \
-               : [vs] "v"(vs), [mu] "v"(mu), [b0] "v"(Bc[3 * (S)]), [b1] "v"(Bc[3 * (S) + 1]), [b2] "v"(Bc[3 * (S) + 2]), \
-                 [nrm] "s"(nrm_mask), [ln] "n"(KROW_LANE(3 * (S))), [lx] "n"(KROW_LANE(3 * (S) + 1)),      \
-                 [ly] "n"(KROW_LANE(3 * (S) + 2))                                                      \
+               #P ":\n\t"
+#define TREX_POINT_OUTS [y] "+v"(y), [lam] "+v"(lam), [al] "+s"(alive), [t] "=&v"(pt_), [d] "=&v"(pd_), [hi] "=&v"(ph_), \
+                        [snl] "=&s"(psn_), [sd] "=&s"(psd_), [tmp] "=&s"(ptm_)
+#define TREX_POINT_INS [vs] "v"(vs), [mu] "v"(mu), [nrm] "s"(nrm_mask)
+#define TREX_POINT_OPS(P, S) [b0##P] "v"(Bc[3 * (S)]), [b1##P] "v"(Bc[3 * (S) + 1]), [b2##P] "v"(Bc[3 * (S) + 2]),     \
+                             [ln##P] "n"(KROW_LANE(3 * (S))), [lx##P] "n"(KROW_LANE(3 * (S) + 1)), [ly##P] "n"(KROW_LANE(3 * (S) + 2))
+// (several point slots per asm statement: the compiler closes every statement with an s_nop of its own)
+#define TREX_POINTS3(S)                                                                                \
+  asm volatile(TREX_POINT_TEXT(0) TREX_POINT_TEXT(1) TREX_POINT_TEXT(2)                                \
+               : TREX_POINT_OUTS                                                                       \
+               : TREX_POINT_INS, TREX_POINT_OPS(0, S), TREX_POINT_OPS(1, (S) + 1), TREX_POINT_OPS(2, (S) + 2) \
                : "vcc", "scc");
+#define TREX_POINTS1(S)                                                                                \
+  asm volatile(TREX_POINT_TEXT(0) : TREX_POINT_OUTS : TREX_POINT_INS, TREX_POINT_OPS(0, S) : "vcc", "scc");
       // lanes that hold the normal row of a live point slot
       const unsigned long long nrm_mask = __ballot(lt >= CLANE0 && (lt - CLANE0) % 3 == 0 && (lt - CLANE0) / 3 >= s0);
       auto alive_points = [&]() { return nrm_mask & (__ballot(lam != 0.f) | __ballot(lam + y > 0.f)); };   // (two v_cmp + s_or)
@@ -1669,13 +1676,15 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
           float pt_, pd_, ph_;
           int psn_, psd_;
           unsigned long long ptm_;
-          if (s0 < 7) { TREX_POINT(0) TREX_POINT(1) TREX_POINT(2) TREX_POINT(3) TREX_POINT(4) TREX_POINT(5) TREX_POINT(6) }
-          if (s0 < 10) { TREX_POINT(7) TREX_POINT(8) TREX_POINT(9) }
-          TREX_POINT(10) TREX_POINT(11) TREX_POINT(12)
+          if (s0 < 7) { TREX_POINTS3(0) TREX_POINTS3(3) TREX_POINTS1(6) }
+          if (s0 < 10) { TREX_POINTS3(7) }
+          TREX_POINTS3(10)
         }
       }
 #undef TREX_ROW
-#undef TREX_POINT
+#undef TREX_POINT_TEXT
+#undef TREX_POINTS3
+#undef TREX_POINTS1
       lam -= lam_c;
     }
 #if TREX_PRIO_MODE == 1 || TREX_PRIO_MODE == 3 || TREX_PRIO_MODE == 6
