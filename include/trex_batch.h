@@ -129,9 +129,11 @@ int trex_batch_step(TrexBatch *batch, const float *actions_dev, float *obs_dev, 
 /* The same two calls writing ONE row block (what the multi-GPU exchange gathers):
  *   rows_dev [N, row_stride] f32 device, row_stride >= 3J + 2:
  *     [0, 3J) observation, [3J] reward, [3J+1] done as 0.0 / 1.0; columns beyond 3J+2 are not touched.
- * trex_batch_reset_rows writes the observation columns only (of every env, reset or not). */
+ * done_dev [N] u8, nullable: the done flags once more as bytes (what a consumer masks with - saves it a
+ *   conversion pass over the column). trex_batch_reset_rows writes the observation columns only (of every env,
+ *   reset or not). */
 int trex_batch_step_rows(TrexBatch *batch, const float *actions_dev, float *rows_dev, int row_stride,
-                         float *penalties_dev, void *stream);
+                         float *penalties_dev, uint8_t *done_dev, void *stream);
 int trex_batch_reset_rows(TrexBatch *batch, const uint8_t *mask_dev, float *rows_dev, int row_stride, void *stream);
 
 /* Episode limit of the harness. The reference env never terminates (should_terminate() is constant False,

@@ -485,7 +485,7 @@ int trex_batch_step(TrexBatch *b, const float *actions_dev, float *obs_dev, floa
 }
 
 int trex_batch_step_rows(TrexBatch *b, const float *actions_dev, float *rows_dev, int row_stride, float *penalties_dev,
-                         void *stream) {
+                         uint8_t *done_dev, void *stream) {
   if (check_batch(b)) return TREX_E_INVALID;
   if (!actions_dev || !rows_dev) return fail(TREX_E_INVALID, "trex_batch_step_rows: null argument");
   if (row_stride < 3 * b->nj + 2) return fail(TREX_E_INVALID, "trex_batch_step_rows: row_stride < 3J + 2");
@@ -494,8 +494,9 @@ int trex_batch_step_rows(TrexBatch *b, const float *actions_dev, float *rows_dev
   BUF_TRY(actions_dev, n * b->nj * sizeof(float), "trex_batch_step_rows: actions");
   BUF_TRY(rows_dev, ((n - 1) * row_stride + 3 * b->nj + 2) * sizeof(float), "trex_batch_step_rows: rows");
   BUF_TRY(penalties_dev, n * 3 * sizeof(float), "trex_batch_step_rows: penalties");
+  BUF_TRY(done_dev, n, "trex_batch_step_rows: done");
   float *rew = rows_dev + 3 * b->nj;
-  HIP_TRY(trex_launch_step(b->dmodel, b->arr, b->n, actions_dev, rows_dev, rew, nullptr, penalties_dev, b->wd, b->we,
+  HIP_TRY(trex_launch_step(b->dmodel, b->arr, b->n, actions_dev, rows_dev, rew, done_dev, penalties_dev, b->wd, b->we,
                            b->wk, nullptr, (hipStream_t)stream, rew + 1, row_stride, row_stride));
   return TREX_OK;
 }

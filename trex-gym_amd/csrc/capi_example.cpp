@@ -49,7 +49,7 @@ int main(int argc, char **argv) {
     const int e1 = trex_batch_step(batch, a.data(), obs, rew, done, nullptr, stream);        // host actions
     const int e2 = trex_batch_step(batch, act, host_obs.data(), rew, done, nullptr, stream);  // host obs
     const int e3 = trex_batch_step(batch, act, obs, small, done, nullptr, stream);            // reward buffer too short
-    const int e4 = trex_batch_step_rows(batch, act, obs, 3 * J, nullptr, stream);             // row stride < 3J + 2
+    const int e4 = trex_batch_step_rows(batch, act, obs, 3 * J, nullptr, nullptr, stream);             // row stride < 3J + 2
     if (e1 != TREX_E_INVALID || e2 != TREX_E_INVALID || e3 != TREX_E_INVALID || e4 != TREX_E_INVALID) {
       std::fprintf(stderr, "bad buffers were not refused: %d %d %d %d\n", e1, e2, e3, e4);
       return 1;

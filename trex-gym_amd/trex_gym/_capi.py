@@ -65,7 +65,7 @@ lib.trex_batch_num_envs.argtypes = [_vp]
 lib.trex_batch_set_reward_weights.argtypes = [_vp, C.c_float, C.c_float, C.c_float]
 lib.trex_batch_reset.argtypes = [_vp, _vp, _vp, _vp]
 lib.trex_batch_step.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp]
-lib.trex_batch_step_rows.argtypes = [_vp, _vp, _vp, C.c_int, _vp, _vp]
+lib.trex_batch_step_rows.argtypes = [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp]
 lib.trex_batch_reset_rows.argtypes = [_vp, _vp, _vp, C.c_int, _vp]
 lib.trex_batch_set_episode_limit.argtypes = [_vp, C.c_int, _vp, _vp]
 lib.trex_batch_get_episode_steps.argtypes = [_vp, _vp, _vp]
@@ -256,12 +256,17 @@ class Batch:
                                   self._p(reward, "float32", n, "reward"), self._p(done, "uint8", n, "done"),
                                   self._p(penalties, "float32", 3 * n, "penalties"), self._stream(stream)))
 
-    def step_rows(self, actions, rows, penalties=None, stream=None):
-        """One step writing the [n, stride] row block obs | reward | done (stride = rows.shape[1] >= 3J + 2)."""
+    def step_rows(self, actions, rows, penalties=None, stream=None, done=None):
+        """One step writing the [n, stride] row block obs | reward | done (stride = rows.shape[1] >= 3J + 2);
+        done [n] uint8 or bool, optional: the flags once more as bytes."""
+        import torch
         n, J = self.num_envs, self.J
+        if done is not None and done.dtype not in (torch.uint8, torch.bool):
+            raise TrexError(E_INVALID, "done: expected dtype uint8 or bool, got %s" % done.dtype)
         check(lib.trex_batch_step_rows(self.h, self._p(actions, "float32", n * J, "actions"),
                                        self._p(rows, "float32", n * (3 * J + 2), "rows"), int(rows.shape[1]),
-                                       self._p(penalties, "float32", 3 * n, "penalties"), self._stream(stream)))
+                                       self._p(penalties, "float32", 3 * n, "penalties"),
+                                       _ptr(done, self.device, None, n, "done"), self._stream(stream)))
 
     def reset_rows(self, rows, mask=None, stream=None):
         n, J = self.num_envs, self.J

@@ -10,7 +10,7 @@ harness's: `max_episode_steps` (None = never) auto-resets like a VecEnv does and
 inside the step launch itself (trex_batch_set_episode_limit).
 
 Outputs live in ONE row block `rows` [n, 3J+2] f32 = obs | reward | done (written by the kernel in that
-layout: trex_batch_step_rows); `obs`, `rew` and `done_f` are views into it.
+layout: trex_batch_step_rows); `obs`, `rew` and `done_f` are views into it; `done` holds the flags as bool.
 
 Multi-GPU: one process per GPU, env ids sharded by contiguous range (trex_gym.sharding); the only
 exchange is the all-gather of that row block (all_gather_rows / all_gather_rows_pipelined).
@@ -66,6 +66,7 @@ class TrexVecEnv:
         self.obs = self.rows[:, :3 * J]
         self.rew = self.rows[:, 3 * J]
         self.done_f = self.rows[:, 3 * J + 1]
+        self.done = torch.zeros(n, dtype=torch.bool, device=self.device)   # the same flags as bytes (written by the kernel too)
         self.penalties = torch.zeros(n, 3, device=self.device)
         self.max_episode_steps = max_episode_steps
         if max_episode_steps is not None:
@@ -101,8 +102,8 @@ class TrexVecEnv:
             raise ValueError("actions must have shape (%d, %d), got %s" % (self.num_envs, self.J, tuple(actions.shape)))
         # (with max_episode_steps the launch also resets the envs whose episode ends with this step: done = 1,
         # reward of the finished step, observation of the new episode - VecEnv semantics, no second launch)
-        self.batch.step_rows(actions, self.rows, self.penalties)
-        return self.obs, self.rew, self.done_f != 0
+        self.batch.step_rows(actions, self.rows, self.penalties, done=self.done)
+        return self.obs, self.rew, self.done
 
     def all_gather_rows(self, rows=None):
         """[global N, 3J+2] = obs | reward | done of EVERY env, on every rank: the one collective of the path
