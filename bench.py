@@ -290,8 +290,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": "trex_step_kernel<false, false>", "kernel_ms": kernel_ms,
-                         "kernel_ms_covers": "one step launch (balance kernel, about 6 us, + trex_step_kernel<false, false>, "
-                                             "which also resets the envs whose episode ends), bracketed by HIP events",
+                         "kernel_ms_covers": "one step launch = ONE kernel, trex_step_kernel<false, false> (it ranks the envs for the next launch and "
+                                             "resets the envs whose episode ends), bracketed by HIP events",
                          "alg_bytes_per_launch": alg, "kernel_build": build_id,
                          "note": "latency/VALU-bound by construction (serial PGS); HBM fraction reported as "
                                  "BASELINE asks, roofline_issue is the bound that matters (DESIGN.md)"},

@@ -30,6 +30,8 @@ def main():
     lines += ["", "step kernel `trex_step_kernel<false, false>`: %d dispatches; timed region (last %d): avg %.3f ms, min %.3f, max %.3f"
               % (len(d), len(timed), sum(timed) / len(timed) / 1e6, min(timed) / 1e6, max(timed) / 1e6)]
     pk = [r for r in csv.DictReader(open(trace)) if "trex_balance_kernel" in r["Kernel_Name"]]
+    if not pk:
+        lines.append("step launch = this ONE kernel (the env-to-wave assignment is made inside it); bench.py brackets it with HIP events")
     if pk:
         pk.sort(key=lambda r: int(r["Start_Timestamp"]))
         pd = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in pk][-steps:]

@@ -397,7 +397,7 @@ int trex_batch_create(const TrexModel *model, int num_envs, int device, TrexBatc
   A(n, (void **)&b->arr.motors_on);
   A(n * sizeof(int32_t), (void **)&b->arr.contact_count);
   A(n * sizeof(float), (void **)&b->arr.normal_impulse);
-  A(n * sizeof(int32_t), (void **)&b->arr.pair_perm);
+  A(TREX_BAL_WORDS(n) * sizeof(int32_t), (void **)&b->arr.balance);
   A(n * sizeof(int32_t), (void **)&b->arr.episode_steps);
   b->arr.max_episode_steps = 0;
   size_t nv = model->host.hull_xyz.size();
@@ -420,6 +420,12 @@ int trex_batch_create(const TrexModel *model, int num_envs, int device, TrexBatc
   if (r == hipSuccess) r = hipMemcpy(link_tf_dev, ltf.data(), ltf.size() * sizeof(float), hipMemcpyHostToDevice);
   if (r == hipSuccess) r = hipMemcpy(b->dmodel, &dm, sizeof dm, hipMemcpyHostToDevice);
   if (r == hipSuccess) r = hipMemcpy(b->arr.hull, hull.data(), hull.size() * sizeof(float4), hipMemcpyHostToDevice);
+  {   // wave balance: before the first step launch every env is filed under contact count 0, in env order
+    std::vector<int32_t> bal(TREX_BAL_LISTS + n, 0);
+    bal[TREX_BAL_COUNTS + 0] = (int32_t)n;
+    for (size_t i = 0; i < n; i++) bal[TREX_BAL_LISTS + i] = (int32_t)i;
+    if (r == hipSuccess) r = hipMemcpy(b->arr.balance, bal.data(), bal.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+  }
   if (r == hipSuccess) r = trex_launch_fill(b->arr.mass_scale, 1.0f, num_envs * TREX_TL, nullptr);
   if (r == hipSuccess) r = trex_launch_fill(b->arr.friction, (float)model->host.prm.friction, num_envs, nullptr);
   if (r == hipSuccess) r = hipDeviceSynchronize();

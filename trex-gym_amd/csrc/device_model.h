@@ -47,12 +47,22 @@ struct TrexDeviceModel {
  *   base  [N][16]  pos(3) quat xyzw(4) v(3) w(3) pad(3)
  *   q, qd, tau, mass_scale  [N][32]  indexed by BODY lane (lane 0 unused)
  *   friction [N], motors_on [N] (u8), contact stats [N] */
+#define TREX_BAL_PHASE 0
+#define TREX_BAL_FINISHED 1
+#define TREX_BAL_COUNTS 16
+#define TREX_BAL_BINS 16
+#define TREX_BAL_LISTS 48
+#define TREX_BAL_WORDS(n) (TREX_BAL_LISTS + 2 * TREX_BAL_BINS * (size_t)(n))
+
 struct TrexBatchArrays {
   float *base, *q, *qd, *tau, *mass_scale, *friction;
   uint8_t *motors_on;
   int32_t *contact_count;
   float *normal_impulse;
-  int32_t *pair_perm;     /* [N] wave slot -> env id: envs ranked by their last contact count (wave balance) */
+  int32_t *balance;       /* wave balance, device-side state only: [TREX_BAL_PHASE] which of the two list sets the next
+                             step launch reads, [TREX_BAL_FINISHED] waves of the running launch that have ended,
+                             [TREX_BAL_COUNTS + 16 p + c] envs filed under contact count c in set p,
+                             [TREX_BAL_LISTS + (16 p + c) N + i] the i-th of them */
   int32_t *episode_steps; /* [N] env-steps since the env's last reset (the harness's episode limit) */
   int32_t max_episode_steps;  /* 0 = no limit; > 0: an env whose count reaches it is reset INSIDE the step launch */
   int32_t pad_;

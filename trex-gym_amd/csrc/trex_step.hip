@@ -342,7 +342,7 @@ struct KernelArgs {
   int obs_stride, scal_stride;
   float *penalties;       // [N, 3] nullable
   const uint8_t *reset_mask;  // RESET only, nullable = all
-  const int32_t *perm;        // wave slot -> env id (step launches), nullable = identity
+  int32_t *bal;               // rank lists of the wave balance (step launches), nullable = workgroup k runs env k
   float w_distance, w_energy, w_drift;
   float *debug;           // diagnostics of env 0's last substep (tests), nullable
 };
@@ -356,8 +356,32 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
   __shared__ WaveLds W;
   const int tid = threadIdx.x;
   const TrexDeviceModel *__restrict__ M = args.model;
+  // Which env this wave runs. All waves of the headline launch are resident at once and a SIMD is done when its
+  // slowest wave is, so the envs are dealt by the contact count of their PREVIOUS step launch: every wave filed its
+  // env under its count at the end of that launch (below), and wave k now takes rank r(k) of those lists, heaviest
+  // count first. Ranks 0..1023 go to workgroups 0..1023 in order, every later block of 1024 in REVERSE: SIMD j
+  // (workgroups j, 1024 + j, ...) gets the j-th heaviest env together with the j-th lightest of each later block -
+  // the sums of work per SIMD are level. Device-side state only (phase, counts, lists): nothing to launch before
+  // the step, and a captured graph replays correctly.
   int env = blockIdx.x;
-  if (args.perm) env = args.perm[env];
+  int bal_phase = 0;
+  if (args.bal) {
+    const int32_t *B = args.bal;
+    bal_phase = uni(B[TREX_BAL_PHASE]);
+    const int32_t *cnt = B + TREX_BAL_COUNTS + TREX_BAL_BINS * bal_phase;
+    const int k = (int)blockIdx.x, q = k >> 10, m = min(1024, args.n_envs - (q << 10));
+    int r = q == 0 ? k : (q << 10) + (m - 1 - (k & 1023));
+    const int lane_ = (int)threadIdx.x;
+    const int mine = lane_ < TREX_BAL_BINS ? cnt[lane_] : 0;   // the 16 counts in one load, lane c holds count c
+    int b = TREX_BAL_BINS - 1;
+    for (; b > 0; b--) {
+      const int c = rl(mine, b);
+      if (r < c) break;
+      r -= c;
+    }
+    env = B[TREX_BAL_LISTS + (size_t)(bal_phase * TREX_BAL_BINS + b) * args.n_envs + r];
+    env = min(max(env, 0), args.n_envs - 1);
+  }
   env = uni(env);
 
   const int nb = M->nb, maxdepth = M->maxdepth;
@@ -1830,6 +1854,23 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
       args.penalties[env * 3 + 0] = env_bad ? 0.f : lift; args.penalties[env * 3 + 1] = env_bad ? 0.f : drift;
       args.penalties[env * 3 + 2] = env_bad ? 0.f : energy;
     }
+    if (!RESET && args.bal) {
+      // file this env under its contact count for the next launch (the other phase's lists); the LAST wave of the
+      // launch - every wave has read the phase and filed its env by then - clears the counts this launch read and
+      // flips the phase
+      int32_t *B = args.bal;
+      const int w = bal_phase ^ 1;
+      const int bin = stat_nc < 0 ? 0 : (stat_nc >= TREX_BAL_BINS ? TREX_BAL_BINS - 1 : stat_nc);
+      const int at = atomicAdd(&B[TREX_BAL_COUNTS + TREX_BAL_BINS * w + bin], 1);
+      if (at < args.n_envs) B[TREX_BAL_LISTS + (size_t)(w * TREX_BAL_BINS + bin) * args.n_envs + at] = env;
+      // (no fence: the lists are read by the NEXT launch only; within this launch the last wave needs nothing but
+      // the count of ended waves, an atomic)
+      if (atomicAdd(&B[TREX_BAL_FINISHED], 1) == args.n_envs - 1) {
+        B[TREX_BAL_FINISHED] = 0;
+        for (int i = 0; i < TREX_BAL_BINS; i++) B[TREX_BAL_COUNTS + TREX_BAL_BINS * bal_phase + i] = 0;
+        B[TREX_BAL_PHASE] = w;
+      }
+    }
   }
 }
 
@@ -1973,49 +2014,15 @@ __global__ void trex_copy_mass_scale_kernel(const float *src, float *dst, int n,
   dst[i] = l < nb ? src[e * nb + l] : 1.0f;
 }
 
-// Wave balance. All waves of the headline launch are resident at once (4096 envs = 4 waves on each of the 1024
-// SIMDs) and a SIMD is done when its slowest wave is: an env with many contact rows takes up to twice as long
-// as an airborne one. Workgroup k lands on SIMD k mod 1024 (up to a permutation: profiles/tools/census.hip),
-// so with the envs RANKED by the contact count of their previous step and workgroup k taking rank k, every
-// SIMD gets one env of each quarter of the ranking - never two heavy ones. (Counting sort, 16 bins, one
-// workgroup; the physics of an env does not depend on its slot: tests/ permutation equivariance.)
-__global__ __launch_bounds__(1024) void trex_balance_kernel(const int32_t *contact_count, int32_t *perm, int n) {
-  __shared__ int hist[16], start[16], fill[16];
-  const int t = threadIdx.x;
-  if (t < 16) { hist[t] = 0; fill[t] = 0; }
-  __syncthreads();
-  for (int i = t; i < n; i += 1024) {
-    const int c = contact_count[i];
-    atomicAdd(&hist[c < 0 ? 0 : (c > 15 ? 15 : c)], 1);
-  }
-  __syncthreads();
-  if (t == 0) {
-    int acc = 0;
-    for (int b = 15; b >= 0; b--) { start[b] = acc; acc += hist[b]; }   // heaviest first
-  }
-  __syncthreads();
-  for (int i = t; i < n; i += 1024) {
-    const int c = contact_count[i];
-    const int b = c < 0 ? 0 : (c > 15 ? 15 : c);
-    // rank r (0 = heaviest) -> workgroup: the first 1024 ranks in order, every later block of 1024 REVERSED, so
-    // that SIMD j (workgroups j, 1024 + j, ...) gets the j-th heaviest env together with the j-th LIGHTEST of each
-    // later block - the sums of work per SIMD are level, not only the heaviest env of each
-    const int r = start[b] + atomicAdd(&fill[b], 1);
-    const int q = r >> 10, m = min(1024, n - (q << 10));
-    perm[q == 0 ? r : (q << 10) + (m - 1 - (r & 1023))] = i;
-  }
-}
-
 // ---------------------------------------------------------------- host launchers (called by capi.cpp)
 extern "C" {
 
 hipError_t trex_launch_step(const TrexDeviceModel *model, TrexBatchArrays arr, int n, const float *actions,
                             float *obs, float *reward, uint8_t *done, float *penalties, float wd, float we,
                             float wk, float *debug, hipStream_t stream, float *done_f, int obs_stride, int scal_stride) {
-  // diagnostics launches keep env 0 in workgroup 0 (the stamped build is balanced like the product: it reports
+  // diagnostics launches keep env k in workgroup k (the stamped build is balanced like the product: it reports
   // the env of every wave)
-  const int32_t *perm = ((debug && !TREX_STAMPS) || n < 2048 || getenv("TREX_NO_BALANCE")) ? nullptr : arr.pair_perm;
-  if (perm) hipLaunchKernelGGL(trex_balance_kernel, dim3(1), dim3(1024), 0, stream, arr.contact_count, arr.pair_perm, n);
+  int32_t *perm = ((debug && !TREX_STAMPS) || n < 2048 || getenv("TREX_NO_BALANCE")) ? nullptr : arr.balance;
   KernelArgs a{model, arr, n, actions, obs, reward, done, done_f, obs_stride, scal_stride, penalties, nullptr, perm, wd, we, wk, debug};
 #if TREX_STAMPS   // diagnostic build: the PRODUCT instantiation, stamped (the dump of <false, true> would change its code)
   hipLaunchKernelGGL((trex_step_kernel<false, false>), dim3(n), dim3(64), 0, stream, a);
