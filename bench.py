@@ -158,7 +158,7 @@ def main():
     n_global = args.envs_per_gpu * world
     overrides = {k: float(v) for k, v in (p.split("=") for p in args.param)}
     env = TrexVecEnv(n_global, device=dev, rank=rank, world_size=world, params=overrides, collision=args.collision,
-                     max_episode_steps=EPISODE_STEPS)
+                     max_episode_steps=EPISODE_STEPS, row_buffers=2 if (world > 1 or under_launcher) else 1)
     if args.collision != "hulls":
         overrides = dict(overrides, collision=args.collision)
     n_local = env.num_envs
@@ -192,7 +192,7 @@ def main():
                 else:
                     env.all_gather_rows()             # blocking: the consumer sees this step's rows
             elif force_gather:   # one-GPU rehearsal of the collective call itself (RCCL, world of 1)
-                pipe.push(env.rows)
+                pipe.push(env.rows, copy=False)
 
     def fence():
         torch.cuda.synchronize()
@@ -201,10 +201,10 @@ def main():
             torch.cuda.synchronize()
 
     def contact_hist():
+        # stays on the device (read back after the timed region: no host round trip between pre-roll and warm-up)
         cnt = torch.zeros(n_local, dtype=torch.int32, device=dev)
         env.batch.contact_stats(cnt, None)
-        h = torch.bincount(cnt.clamp(0, 15).to(torch.int64), minlength=16)
-        return [int(x) for x in h.tolist()[:14]]
+        return torch.bincount(cnt.clamp(0, 15).to(torch.int64), minlength=16)
 
     env.reset_tensor()
     # staggered episodes, keyed by the GLOBAL env id: env i starts i * EPISODE_STEPS / N steps into its episode, so
@@ -234,7 +234,7 @@ def main():
     run(args.steps, t_base + args.warmup, timed=True)
     fence()
     dt = time.perf_counter() - t0
-    hist1 = contact_hist()
+    hist0, hist1 = ([int(x) for x in h.tolist()[:14]] for h in (hist0, contact_hist()))
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

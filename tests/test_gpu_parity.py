@@ -345,6 +345,29 @@ def test_full_clipping_equals_clipped_actions(full):
     assert (o1 == o2).all() and (r1 == r2).all()
 
 
+def test_two_row_blocks_written_in_turn():
+    """row_buffers=2 (what the in-place pipelined gather of bench.py --gpus N relies on): successive steps write two
+    row blocks in turn, the block of the step before last is left alone, results equal the one-block env's."""
+    n = 256
+    one, two = make_vec(n, max_episode_steps=7), make_vec(n, max_episode_steps=7, row_buffers=2)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    one.reset_tensor(); two.reset_tensor()
+    blocks = []
+    for t in range(9):      # past the episode limit: the done column is exercised
+        a = (0.3 * torch.randn(n, 25, device=DEV, generator=g)).contiguous()
+        o1, r1, d1 = one.step_tensor(a)
+        o2, r2, d2 = two.step_tensor(a)
+        assert (o1 == o2).all() and (r1 == r2).all() and (d1 == d2).all()
+        assert (two.done_f != 0).equal(d2)
+        if t >= 1:
+            assert two.rows.data_ptr() != blocks[-1][0]            # the other block ...
+            assert torch.equal(blocks[-1][1], blocks[-1][2])       # ... and the previous one was not touched
+        if t >= 2:
+            assert two.rows.data_ptr() == blocks[-2][0]
+        blocks.append((two.rows.data_ptr(), two.rows, two.rows.clone()))
+    assert bool(d2.any()) is False and int(two.episode_steps.max()) <= 7
+
+
 def test_full_masked_reset_and_state_round_trip(full):
     v, lo, hi = full
     g = torch.Generator(device=DEV).manual_seed(3)

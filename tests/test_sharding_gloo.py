@@ -109,7 +109,7 @@ def test_two_rank_gloo_gather_equals_single_process(n_global):
     assert done.tolist() == [(i + steps - 1) % 3 == 0 for i in range(n_global)]
 
 
-def _pipe_worker(rank, world, port, ret):
+def _pipe_worker(rank, world, port, ret, in_place=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -117,14 +117,19 @@ def _pipe_worker(rank, world, port, ret):
     sys.path.insert(0, os.path.join(ROOT, "trex-gym_amd"))
     from trex_gym import sharding
     pipe = sharding.PipelinedGather(3, 5, world, torch.float32, "cpu")
+    blocks = [torch.empty(3, 5), torch.empty(3, 5)]     # in_place: the producer's two row blocks, written in turn
     got = []
     for t in range(4):
         # obs (3 columns) | reward | done packed like the step kernel writes them
         local = sharding.pack_rows(torch.full((3, 3), float(10 * t + rank)), torch.full((3,), float(10 * t + rank)),
                                    torch.full((3,), 10 * t + rank, dtype=torch.int32))
         assert local.shape == (3, 5)
-        prev = pipe.push(local)
-        local.fill_(-1.0)    # the caller may overwrite its rows at once (they were staged)
+        if in_place:
+            blocks[t & 1].copy_(local)                    # "step t" writes block t & 1 ...
+            prev = pipe.push(blocks[t & 1], copy=False)   # ... which is gathered where it lies
+        else:
+            prev = pipe.push(local)
+            local.fill_(-1.0)    # the caller may overwrite its rows at once (they were staged)
         got.append(None if prev is None else prev.clone())
     got.append(pipe.flush().clone())
     if rank == 1:
@@ -133,11 +138,13 @@ def _pipe_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_pipelined_gather_returns_the_previous_step(tmp_path):
-    """The overlapped all-gather of bench.py --gpus N: call t returns the rows of call t-1, from every rank."""
+@pytest.mark.parametrize("in_place", [False, True])
+def test_pipelined_gather_returns_the_previous_step(tmp_path, in_place):
+    """The overlapped all-gather of bench.py --gpus N: call t returns the rows of call t-1, from every rank -
+    staged, or gathered in place from a producer that alternates between two row blocks."""
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_pipe_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    mp.spawn(_pipe_worker, args=(2, _free_port(), ret, in_place), nprocs=2, join=True)
     got = ret["got"]
     assert got[0] is None
     for t in range(1, 5):

@@ -98,13 +98,19 @@ class PipelinedGather:
         self.work = [None, None]
         self.k = 0
 
-    def push(self, local):
-        """Launch the gather of `local`; returns the previous call's gathered rows (None on the first)."""
+    def push(self, local, copy=True):
+        """Launch the gather of `local`; returns the previous call's gathered rows (None on the first).
+        copy=False: `local` is gathered in place - the caller leaves it untouched until the call after the
+        next has returned (a producer that alternates between two row blocks does: TrexVecEnv(row_buffers=2)),
+        and no staging copy sits between two steps on the compute stream."""
         k = self.k
         if self.work[k] is not None:     # the collective that last read stage[k] / wrote out[k]
             self.work[k].wait()
-        self.stage[k].copy_(local)
-        self.work[k] = dist.all_gather_into_tensor(self.out[k], self.stage[k], group=self.group, async_op=True)
+        src = local
+        if copy:
+            self.stage[k].copy_(local)
+            src = self.stage[k]
+        self.work[k] = dist.all_gather_into_tensor(self.out[k], src, group=self.group, async_op=True)
         prev = 1 - k
         self.k = prev
         if self.work[prev] is None:

@@ -29,8 +29,10 @@ class TrexVecEnv:
     def __init__(self, num_envs, urdf_path=None, collisions_dir=None, device=None, action_repeat=1,
                  distance_weight=1.0, energy_weight=0.005, drift_weight=0.002,
                  max_episode_steps=None, starting_configuration=None, params=None,
-                 rank=0, world_size=1, process_group=None, collision="hulls", primitive_max_radius=0.2):
-        """num_envs is the GLOBAL env count; this process owns sharding.shard_range(num_envs, rank, world_size)."""
+                 rank=0, world_size=1, process_group=None, collision="hulls", primitive_max_radius=0.2, row_buffers=1):
+        """num_envs is the GLOBAL env count; this process owns sharding.shard_range(num_envs, rank, world_size).
+        row_buffers=2: successive steps write two row blocks in turn (`rows`, `obs`, `rew`, `done_f` always name the
+        block of the LAST step), which lets the pipelined all-gather read a block in place."""
         self.global_num_envs = int(num_envs)
         self.rank, self.world_size, self.process_group = int(rank), int(world_size), process_group
         self.env_lo, self.env_hi = sharding.shard_range(self.global_num_envs, self.rank, self.world_size)
@@ -62,10 +64,11 @@ class TrexVecEnv:
         self.observation_space = spaces.Box(low=np.concatenate([lo, -big]), high=np.concatenate([hi, big]),
                                             dtype=np.float32)
         n = self.num_envs
-        self.rows = torch.zeros(n, 3 * J + 2, device=self.device)   # obs | reward | done
-        self.obs = self.rows[:, :3 * J]
-        self.rew = self.rows[:, 3 * J]
-        self.done_f = self.rows[:, 3 * J + 1]
+        # obs | reward | done. row_buffers=2: the steps write two blocks in turn, so that a block can be gathered in
+        # place while the next step runs (all_gather_rows_pipelined without a staging copy)
+        self._row_blocks = [torch.zeros(n, 3 * J + 2, device=self.device) for _ in range(int(row_buffers))]
+        self._row_k = 0
+        self._point_at(0)
         self.done = torch.zeros(n, dtype=torch.bool, device=self.device)   # the same flags as bytes (written by the kernel too)
         self.penalties = torch.zeros(n, 3, device=self.device)
         self.max_episode_steps = max_episode_steps
@@ -102,8 +105,16 @@ class TrexVecEnv:
             raise ValueError("actions must have shape (%d, %d), got %s" % (self.num_envs, self.J, tuple(actions.shape)))
         # (with max_episode_steps the launch also resets the envs whose episode ends with this step: done = 1,
         # reward of the finished step, observation of the new episode - VecEnv semantics, no second launch)
+        if len(self._row_blocks) > 1:
+            self._point_at(1 - self._row_k)
         self.batch.step_rows(actions, self.rows, self.penalties, done=self.done)
         return self.obs, self.rew, self.done
+
+    def _point_at(self, k):
+        J = self.J
+        self._row_k = k
+        self.rows = self._row_blocks[k]
+        self.obs, self.rew, self.done_f = self.rows[:, :3 * J], self.rows[:, 3 * J], self.rows[:, 3 * J + 1]
 
     def all_gather_rows(self, rows=None):
         """[global N, 3J+2] = obs | reward | done of EVERY env, on every rank: the one collective of the path
@@ -126,7 +137,7 @@ class TrexVecEnv:
                 raise ValueError("pipelined gather needs equal shards")
             self._pipe = sharding.PipelinedGather(self.num_envs, rows.shape[1], self.world_size, rows.dtype,
                                                   self.device, self.process_group)
-        return self._pipe.push(rows)
+        return self._pipe.push(rows, copy=not (rows is self.rows and len(self._row_blocks) > 1))
 
     def all_gather_obs(self):
         """[global N, 3J]: the observation columns of all_gather_rows()."""
