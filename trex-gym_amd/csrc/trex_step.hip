@@ -673,14 +673,6 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
       const TrexDeviceModel *Mi = Mo();
       const int hull_v0 = Mi->hull_start[is_body ? lt : nb], hull_v1 = Mi->hull_start[is_body ? lt + 1 : nb];
       CgLds &G = *reinterpret_cast<CgLds *>(&W.u);
-      // clear the masks and the minima
-      {
-        unsigned *z = &G.cm[0][0];
-#pragma unroll
-        for (int i = 0; i < (TL * CG_WORDS + 63) / 64; i++)
-          if (lt + 64 * i < TL * CG_WORDS) z[lt + 64 * i] = 0u;
-        if (lt < TL) G.best[lt] = ~0ull;
-      }
       // ---- broad phase, one hull per lane
       const int nchunk = Mi->nchunk;
       const bool is_chunk = lt < nchunk;
@@ -699,6 +691,15 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
         near = cv1 > cv0 && (zbc + cz - reach < margin);
       }
       const unsigned near_mask = (unsigned)__ballot(near);
+      if (near_mask != 0u) {   // (an env with no hull near the floor - every second one under random actions - is done here)
+      // clear the masks and the minima
+      {
+        unsigned *z = &G.cm[0][0];
+#pragma unroll
+        for (int i = 0; i < (TL * CG_WORDS + 63) / 64; i++)
+          if (lt + 64 * i < TL * CG_WORDS) z[lt + 64 * i] = 0u;
+        if (lt < TL) G.best[lt] = ~0ull;
+      }
       // ---- table of the near hulls: position of their first vertex in the list, ... (prefix sum over the set bits)
       int total = 0;
       {
@@ -911,6 +912,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
         }
         nc = nc < maxc ? nc : maxc;
       }
+      }   // near_mask != 0
     }
     nc = uni(nc);
 #if TREX_PRIO_MODE == 2
