@@ -313,6 +313,38 @@ def test_wave_balance_and_contact_budget(full):
     assert (o1 == o2).all() and (r1 == r2).all() and (s1 == v.get_state()).all()
 
 
+@pytest.mark.parametrize("n", [2500, 5000])
+def test_rank_lists_cover_every_env_at_ragged_sizes(n, model):
+    """The env-to-wave assignment is made inside the step kernel from lists the previous launch filed (two list sets,
+    flipped by the last wave to end; blocks of 1024 ranks, the last one partial here): over many launches, through
+    landing, EVERY env must be stepped exactly once per launch - the trajectories equal those of launches that keep
+    env k in workgroup k (TREX_NO_BALANCE), bitwise."""
+    lo = torch.tensor(model["q_lower"][model["obs_order"]], dtype=torch.float32, device=DEV)
+    hi = torch.tensor(model["q_upper"][model["obs_order"]], dtype=torch.float32, device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    acts = [(lo + (hi - lo) * torch.rand(n, 25, device=DEV, generator=g)).contiguous() for _ in range(70)]
+
+    def run(no_balance):
+        if no_balance:
+            os.environ["TREX_NO_BALANCE"] = "1"
+        try:
+            v = make_vec(n, max_episode_steps=50)
+            v.reset_tensor()
+            v.set_episode_steps(torch.arange(n, device=DEV, dtype=torch.int32) % 50)   # resets inside the launches, too
+            for a in acts:
+                o, r, d = v.step_tensor(a)
+            cnt = torch.zeros(n, dtype=torch.int32, device=DEV)
+            v.batch.contact_stats(cnt, None)
+            return o.clone(), r.clone(), v.get_state().clone(), cnt
+        finally:
+            os.environ.pop("TREX_NO_BALANCE", None)
+
+    o1, r1, s1, c1 = run(False)
+    o2, r2, s2, c2 = run(True)
+    assert int(c1.max()) >= 6 and int(c1.min()) == 0          # the counts that drive the ranking did spread
+    assert (o1 == o2).all() and (r1 == r2).all() and (s1 == s2).all() and (c1 == c2).all()
+
+
 def test_bad_tensors_are_refused(full, capi):
     """Host memory, a wrong dtype, a short or non-contiguous buffer would be misread or fault the GPU:
     the binding refuses them with TREX_E_INVALID (and the C-ABI checks raw pointers again:
