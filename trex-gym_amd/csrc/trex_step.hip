@@ -49,14 +49,8 @@
 #ifndef TREX_STAMPS
 #define TREX_STAMPS 0
 #endif
-#ifndef TREX_PRIO_HEAVY
-#define TREX_PRIO_HEAVY 9
-#endif
-#ifndef TREX_PRIO_HEAVY_LEVEL
-#define TREX_PRIO_HEAVY_LEVEL 3
-#endif
 #ifndef TREX_PRIO_MODE
-#define TREX_PRIO_MODE 1   // 0 none, 1 by contact count during the sweeps only, 2 for the whole substep
+#define TREX_PRIO_MODE 1   // 0: no priorities (ablation), 1: the policy described at set_sweep_priority
 #endif
 // Diagnostic build only (make stamps): s_memtime at phase boundaries of workgroup 0, accumulated into the
 // debug buffer at [3000 + phase] as cycles. Never compiled into the product library.
@@ -463,28 +457,33 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
   // many contact rows. During its sweeps such a wave wins the issue arbitration against the lighter waves of
   // its SIMD, which fill the slots its dependency chain leaves empty. (Mode 2, priority for the whole substep,
   // starved the light waves instead: 3.84 M against 4.12 M env-steps/s.)
+  // ---- issue priority. The SIMD's arbiter serves the highest s_setprio level first and, within a level, the OLDEST
+  // wave. Measured (bench.py, 4096 envs): no priorities 8.5 M env-steps/s; waves with contact rows
+  // first during their sweeps (levels by contact count) 9.5 M - their row chains are the longest; and on top of that
+  // the age rule has to be countered: workgroup k sits on SIMD k mod 1024, so the waves of workgroup blocks 2 and 3
+  // are the two YOUNGEST of their SIMD and lose every tie - they ended 0.2 M cycles after their mates and the SIMD
+  // ran one wave for a fifth of the launch. They get one level more in three of every four blocks of 8 sweeps, and
+  // level 1 instead of 0 outside the sweeps: 9.9 M. (Not better: the bump always or half of the time, for three
+  // waves instead of two, +2, a rotating top wave, distinct static levels per wave, levels outside the sweeps by
+  // contact count.)
 #ifndef TREX_PRIO_T1
 #define TREX_PRIO_T1 1
 #define TREX_PRIO_T2 3
 #define TREX_PRIO_T3 6
 #endif
-  auto set_priority = [](int contacts) {
-    if (contacts >= TREX_PRIO_T3) __builtin_amdgcn_s_setprio(3);
-    else if (contacts >= TREX_PRIO_T2) __builtin_amdgcn_s_setprio(2);
-    else if (contacts >= TREX_PRIO_T1) __builtin_amdgcn_s_setprio(1);
-    else __builtin_amdgcn_s_setprio(0);
+  // (only where the launch is resident at once, 4096 envs or fewer: beyond that a workgroup's index says nothing
+  // about its age among the waves of its SIMD)
+  const bool young_wave = args.n_envs <= 4096 && ((int)blockIdx.x >> 10) >= 2;
+  auto set_sweep_priority = [&](int contacts, int block) {
+    int v = contacts >= TREX_PRIO_T3 ? 3 : (contacts >= TREX_PRIO_T2 ? 2 : (contacts >= TREX_PRIO_T1 ? 1 : 0));
+    v += (young_wave && (block & 3) != 0) ? 1 : 0;
+    if (v <= 0) __builtin_amdgcn_s_setprio(0);
+    else if (v == 1) __builtin_amdgcn_s_setprio(1);
+    else if (v == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
   };
-#if TREX_PRIO_MODE == 2
-  if (!RESET) set_priority(uni(args.arr.contact_count[env]));
-#endif
-#if TREX_PRIO_MODE == 4
-  if (!RESET && uni(args.arr.contact_count[env]) >= TREX_PRIO_HEAVY) __builtin_amdgcn_s_setprio(TREX_PRIO_HEAVY_LEVEL);
-#endif
-#if TREX_PRIO_MODE == 5
-  __builtin_amdgcn_s_setprio(3);
-#endif
-#if TREX_PRIO_MODE == 7
-  { const int q_ = (int)(blockIdx.x >> 10); if (q_ == 0) __builtin_amdgcn_s_setprio(3); else if (q_ == 1) __builtin_amdgcn_s_setprio(2); else if (q_ == 2) __builtin_amdgcn_s_setprio(1); }
+#if TREX_PRIO_MODE == 1
+  if (!RESET && young_wave) __builtin_amdgcn_s_setprio(1);
 #endif
 
   const float floor_z = M->prm[TP_FLOOR_Z], margin = M->prm[TP_CONTACT_MARGIN];
@@ -616,9 +615,6 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
     bool is_body, is_joint;
 #define RELANE() do { lt = lane_id(); bl = lt & (TL - 1); is_body = lt < nb; is_joint = lt >= 1 && lt < nb; } while (0)
     RELANE();
-#if TREX_PRIO_MODE == 3
-    set_priority(sub == 0 ? uni(args.arr.contact_count[env]) : stat_nc);
-#endif
     int psrc, depth;
     {
       const TrexDeviceModel *Mi = Mo();
@@ -915,12 +911,6 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
       }   // near_mask != 0
     }
     nc = uni(nc);
-#if TREX_PRIO_MODE == 2
-    set_priority(nc);
-#endif
-#if TREX_PRIO_MODE == 3
-    __builtin_amdgcn_s_setprio(0);
-#endif
     STAMP(1);
     RELANE();
     RETREE();
@@ -1445,17 +1435,6 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
     // Row order (the oracle's): limit rows (ascending joint), motor rows, then per point normal, friction x, y.
     float lam = 0.f, lam_c = 0.f, lim_lam = 0.f;
     int dvec = 0;   // lane j: the impulse change of motor row j in the current sweep (the other lanes stay 0)
-#if TREX_PRIO_MODE == 1 || TREX_PRIO_MODE == 3 || TREX_PRIO_MODE == 4
-    set_priority(nc);
-#endif
-#if TREX_PRIO_MODE == 6
-    { const int q_ = (int)(blockIdx.x >> 10); if (q_ == 0) __builtin_amdgcn_s_setprio(3); else if (q_ == 1) __builtin_amdgcn_s_setprio(2); else if (q_ == 2) __builtin_amdgcn_s_setprio(1); }
-#endif
-#if TREX_PRIO_MODE == 5
-    if (nc >= TREX_PRIO_T2) __builtin_amdgcn_s_setprio(2);
-    else if (nc >= TREX_PRIO_T1) __builtin_amdgcn_s_setprio(1);
-    else __builtin_amdgcn_s_setprio(0);
-#endif
     {
 #define TREX_ROW(LANE, BCOL, LO, HI)                                                                   \
   {                                                                                                    \
@@ -1531,6 +1510,9 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
         // of the loop and spilled. (A lane mask built on the scalar unit - s_lshl_b64 + v_cndmask - measured
         // SLOWER than v_cmp + v_cndmask: 17.6 against 15.2 cycles per row and SIMD at 4 waves per SIMD,
         // profiles/tools/row_bench.hip.)
+#if TREX_PRIO_MODE == 1
+        if ((it & 7) == 0) set_sweep_priority(nc, it >> 3);
+#endif
         int vs = lt;
         asm volatile("" : "+v"(vs));
         // limit rows: the row of joint j rides on motor lane j, whose y gives dv_j / diag = rhs - y
@@ -1713,14 +1695,8 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
 #undef TREX_POINTS1
       lam -= lam_c;
     }
-#if TREX_PRIO_MODE == 1 || TREX_PRIO_MODE == 3 || TREX_PRIO_MODE == 6
-    __builtin_amdgcn_s_setprio(0);
-#endif
-#if TREX_PRIO_MODE == 4
-    if (nc >= TREX_PRIO_HEAVY) __builtin_amdgcn_s_setprio(TREX_PRIO_HEAVY_LEVEL); else __builtin_amdgcn_s_setprio(0);
-#endif
-#if TREX_PRIO_MODE == 5
-    __builtin_amdgcn_s_setprio(3);
+#if TREX_PRIO_MODE == 1
+    if (young_wave) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
 #endif
     STAMP(7);
     RELANE();
