@@ -1504,15 +1504,19 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
       // lanes that hold the normal row of a live point slot
       const unsigned long long nrm_mask = __ballot(lt >= CLANE0 && (lt - CLANE0) % 3 == 0 && (lt - CLANE0) / 3 >= s0);
       auto alive_points = [&]() { return nrm_mask & (__ballot(lam != 0.f) | __ballot(lam + y > 0.f)); };   // (two v_cmp + s_or)
+      // (blocks of 8 sweeps: the issue priority is set per block, no test per sweep)
 #pragma unroll 1
-      for (int it = 0; it < iters; it++) {
+      for (int it0 = 0; it0 < iters; it0 += 8) {
+#if TREX_PRIO_MODE == 1
+      if ((it0 & 16) == 0) set_sweep_priority(nc, it0 >> 3);   // blocks 0, 1, 4, 5, ...: where the level changes
+#endif
+      const int it1 = it0 + 8 < iters ? it0 + 8 : iters;
+#pragma unroll 1
+      for (int it = it0; it < it1; it++) {
         // the lane id, opaque once per sweep: `vs == j` is then one v_cmp where it is used, not a mask hoisted out
         // of the loop and spilled. (A lane mask built on the scalar unit - s_lshl_b64 + v_cndmask - measured
         // SLOWER than v_cmp + v_cndmask: 17.6 against 15.2 cycles per row and SIMD at 4 waves per SIMD,
         // profiles/tools/row_bench.hip.)
-#if TREX_PRIO_MODE == 1
-        if ((it & 7) == 0) set_sweep_priority(nc, it >> 3);
-#endif
         int vs = lt;
         asm volatile("" : "+v"(vs));
         // limit rows: the row of joint j rides on motor lane j, whose y gives dv_j / diag = rhs - y
@@ -1689,6 +1693,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
           TREX_POINTS3(10)
         }
       }
+      }   // block of 8 sweeps
 #undef TREX_ROW
 #undef TREX_POINT_TEXT
 #undef TREX_POINTS3
