@@ -462,28 +462,33 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
   // first during their sweeps (levels by contact count) 9.5 M - their row chains are the longest; and on top of that
   // the age rule has to be countered: workgroup k sits on SIMD k mod 1024, so the waves of workgroup blocks 2 and 3
   // are the two YOUNGEST of their SIMD and lose every tie - they ended 0.2 M cycles after their mates and the SIMD
-  // ran one wave for a fifth of the launch. They get one level more in three of every four blocks of 8 sweeps, and
-  // level 1 instead of 0 outside the sweeps: 9.9 M. (Not better: the bump always or half of the time, for three
-  // waves instead of two, +2, a rotating top wave, distinct static levels per wave, levels outside the sweeps by
-  // contact count.)
+  // ran one wave for a fifth of the launch. In the sweeps they get one level more (10.1 M); outside the sweeps the
+  // two older and the two younger waves take turns at level 1, substep by substep (10.5 M). (Not better: the bump in
+  // the sweeps half of the time, for three waves instead of two, +2, the pairs taking turns there too, a rotating top
+  // wave, distinct static levels per wave, levels outside the sweeps by contact count or for the young pair only, the
+  // older pair first, a change of places in the middle of the tree phases too, other contact-count thresholds.)
+  // Only where the launch is resident at once, 4096 envs or fewer: beyond that a workgroup's index says nothing
+  // about its age among the waves of its SIMD.
 #ifndef TREX_PRIO_T1
 #define TREX_PRIO_T1 1
 #define TREX_PRIO_T2 3
 #define TREX_PRIO_T3 6
 #endif
-  // (only where the launch is resident at once, 4096 envs or fewer: beyond that a workgroup's index says nothing
-  // about its age among the waves of its SIMD)
-  const bool young_wave = args.n_envs <= 4096 && ((int)blockIdx.x >> 10) >= 2;
-  auto set_sweep_priority = [&](int contacts, int block) {
+  const bool aged_launch = args.n_envs <= 4096;
+  const int wave_pair = ((int)blockIdx.x >> 11) & 1;      // 0: the two older waves of the SIMD, 1: the two younger
+  auto set_sweep_priority = [&](int contacts) {
     int v = contacts >= TREX_PRIO_T3 ? 3 : (contacts >= TREX_PRIO_T2 ? 2 : (contacts >= TREX_PRIO_T1 ? 1 : 0));
-    v += (young_wave && (block & 3) != 0) ? 1 : 0;
+    v += (aged_launch && wave_pair == 1) ? 1 : 0;
     if (v <= 0) __builtin_amdgcn_s_setprio(0);
     else if (v == 1) __builtin_amdgcn_s_setprio(1);
     else if (v == 2) __builtin_amdgcn_s_setprio(2);
     else __builtin_amdgcn_s_setprio(3);
   };
+  auto set_tree_priority = [&](int substep) {   // outside the sweeps: the pairs take turns
+    if (aged_launch && ((wave_pair + substep) & 1)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+  };
 #if TREX_PRIO_MODE == 1
-  if (!RESET && young_wave) __builtin_amdgcn_s_setprio(1);
+  if (!RESET) set_tree_priority(0);
 #endif
 
   const float floor_z = M->prm[TP_FLOOR_Z], margin = M->prm[TP_CONTACT_MARGIN];
@@ -1504,15 +1509,11 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
       // lanes that hold the normal row of a live point slot
       const unsigned long long nrm_mask = __ballot(lt >= CLANE0 && (lt - CLANE0) % 3 == 0 && (lt - CLANE0) / 3 >= s0);
       auto alive_points = [&]() { return nrm_mask & (__ballot(lam != 0.f) | __ballot(lam + y > 0.f)); };   // (two v_cmp + s_or)
-      // (blocks of 8 sweeps: the issue priority is set per block, no test per sweep)
-#pragma unroll 1
-      for (int it0 = 0; it0 < iters; it0 += 8) {
 #if TREX_PRIO_MODE == 1
-      if ((it0 & 16) == 0) set_sweep_priority(nc, it0 >> 3);   // blocks 0, 1, 4, 5, ...: where the level changes
+      set_sweep_priority(nc);
 #endif
-      const int it1 = it0 + 8 < iters ? it0 + 8 : iters;
 #pragma unroll 1
-      for (int it = it0; it < it1; it++) {
+      for (int it = 0; it < iters; it++) {
         // the lane id, opaque once per sweep: `vs == j` is then one v_cmp where it is used, not a mask hoisted out
         // of the loop and spilled. (A lane mask built on the scalar unit - s_lshl_b64 + v_cndmask - measured
         // SLOWER than v_cmp + v_cndmask: 17.6 against 15.2 cycles per row and SIMD at 4 waves per SIMD,
@@ -1693,7 +1694,6 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
           TREX_POINTS3(10)
         }
       }
-      }   // block of 8 sweeps
 #undef TREX_ROW
 #undef TREX_POINT_TEXT
 #undef TREX_POINTS3
@@ -1701,7 +1701,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
       lam -= lam_c;
     }
 #if TREX_PRIO_MODE == 1
-    if (young_wave) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    set_tree_priority(sub);
 #endif
     STAMP(7);
     RELANE();
