@@ -278,7 +278,7 @@ def main():
             "data": "synthetic",
             "rccl_ranks": rccl_ranks,
             "config": {"workload": "%d envs per GPU x %d GPU(s), trex.urdf (26 bodies, 31 dof, 2181 hull "
-                                   "vertices), uniform random actions keyed by global env id, 5 substeps x 60 "
+                                   "vertices), uniform random actions keyed by global env id (16 pre-generated draws per env, cycled), 5 substeps x 60 "
                                    "PGS iterations per step, episode limit %d steps with staggered phases "
                                    "(pre-roll %d untimed steps)%s"
                                    % (args.envs_per_gpu, world, EPISODE_STEPS, args.preroll,
