@@ -22,6 +22,7 @@ def main():
     dev = torch.device("cuda:0")
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     pre = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+    cycle = int(sys.argv[3]) if len(sys.argv) > 3 else 0     # 16: bench.py's actions (16 draws per env, cycled); 0: fresh draws
     m = _capi.Model()
     b = _capi.Batch(m, n)
     obs = torch.zeros(n, 75, device=dev); rew = torch.zeros(n, device=dev); done = torch.zeros(n, dtype=torch.uint8, device=dev)
@@ -31,12 +32,12 @@ def main():
     phase = (ids * 1000) // n
     b.reset(obs)
     for t in range(pre):
-        b.step(sharding.synthetic_actions(ids, t, lo, hi, seed=0, device=dev), obs, rew, done)
+        b.step(sharding.synthetic_actions(ids, t % cycle if cycle else t, lo, hi, seed=0, device=dev), obs, rew, done)
         mk = (phase == ((-(t + 1)) % 1000)).to(torch.uint8)
         if bool(mk.any()):
             b.reset(obs, mk)
     dbg = torch.zeros(4096 + 16 * n, device=dev)
-    b.debug_step(sharding.synthetic_actions(ids, pre, lo, hi, seed=0, device=dev), obs, dbg)
+    b.debug_step(sharding.synthetic_actions(ids, pre % cycle if cycle else pre, lo, hi, seed=0, device=dev), obs, dbg)
     torch.cuda.synchronize()
     cnt = torch.zeros(n, dtype=torch.int32, device=dev)
     b.contact_stats(cnt, None)

@@ -829,6 +829,37 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
         const int wstep = GS >= 32 ? 0 : GS;
         int nsel = act ? 1 : 0;
         bool stop = !act;
+        // A lane with at most CC in-margin vertices (every lane of a body of toe size) loads and places them ONCE and
+        // keeps the positions for all passes: one trip to L2 per substep instead of one per pass, no vertex placed
+        // twice. If any lane holds more (or a body is beyond the mask capacity) the passes re-read, as before.
+        constexpr int CC = 4;
+        const bool cached = __ballot(act && (!masked || __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3) > CC)) == 0ull;
+        float cx[CC][3];
+        int cvx[CC];
+#pragma unroll
+        for (int u = 0; u < CC; u++) { cvx[u] = -1; cx[u][0] = cx[u][1] = cx[u][2] = 0.f; }
+        if (cached) {
+          unsigned c0 = m0, c1 = m1, c2 = m2, c3 = m3;
+          int wb = g & 31;
+          float4 hc[CC];
+#pragma unroll
+          for (int u = 0; u < CC; u++) {
+            if (c0 == 0u) { c0 = c1; c1 = c2; c2 = c3; c3 = 0u; wb += wstep; }   // next word of this lane
+            const int j = c0 != 0u ? (__ffs(c0) - 1) : -1;
+            c0 &= c0 - 1u;            // (0 stays 0)
+            cvx[u] = j >= 0 ? v0 + 32 * j + wb : -1;
+            hc[u] = args.arr.hull[cvx[u] >= 0 ? cvx[u] : v0];
+          }
+#pragma unroll
+          for (int u = 0; u < CC; u++) {
+            const float hv[3] = {hc[u].x, hc[u].y, hc[u].z};
+            float w[3];
+            matvec3(Rb, hv, w);
+            cx[u][0] = rb[0] + w[0]; cx[u][1] = rb[1] + w[1]; cx[u][2] = rb[2] + w[2] - hc[u].w;
+            const float dd = pos[2] + cx[u][2] - floor_z;
+            if (!(dd < margin)) cvx[u] = -1;
+          }
+        }
 #pragma unroll
         for (int pass = 1; pass < 4; pass++) {
           if (pass >= K || __ballot(!stop) == 0ull) break;
@@ -858,7 +889,21 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
             }
             if (score > bs || (score == bs && v < bi)) { bs = score; bi = v; bx[0] = x0; bx[1] = x1; bx[2] = x2; }
           };
-          if (__ballot(act && !masked) == 0ull) {
+          if (cached) {
+#pragma unroll
+            for (int u = 0; u < CC; u++) {
+              const int v = cvx[u];
+              if (v < 0 || stop || v == sel[0] || v == sel[1] || v == sel[2]) continue;
+              const float dx = cx[u][0] - px[0][0], dy = cx[u][1] - px[0][1];
+              float score;
+              if (pass == 1) score = dx * dx + dy * dy;
+              else {
+                const float cr = ex * dy - ey * dx;
+                score = (pass == 2) ? fabsf(cr) : flip * cr;
+              }
+              if (score > bs || (score == bs && v < bi)) { bs = score; bi = v; bx[0] = cx[u][0]; bx[1] = cx[u][1]; bx[2] = cx[u][2]; }
+            }
+          } else if (__ballot(act && !masked) == 0ull) {
             unsigned c0 = stop ? 0u : m0, c1 = stop ? 0u : m1, c2 = stop ? 0u : m2, c3 = stop ? 0u : m3;
             int wb = g & 31;
             constexpr int UC = 2;   // candidates per trip: their loads are issued together
@@ -884,11 +929,15 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
           const float best = gmaxf(bs, GS);
           bi = gmini(bs == best ? bi : 0x7fffffff, GS);
           if (bi == 0x7fffffff || !(best > 0.f)) stop = true;
-          const bool own = !stop && mine == bi;   // exactly one lane of the group
+          const bool own = !stop && mine == bi;   // exactly one lane of the group: its position goes to the group
+          {
+            const unsigned long long ob = __ballot(own) >> (lt & ~(GS - 1));   // bit i: lane i of MY group owns
+            const int src = (lt & ~(GS - 1)) + (ob != 0ull ? __ffsll((unsigned long long)ob) - 1 : 0);
 #pragma unroll
-          for (int c = 0; c < 3; c++) {
-            const float wx = gmaxf(own ? bx[c] : -3.0e38f, GS);
-            if (!stop) px[pass][c] = wx;
+            for (int c = 0; c < 3; c++) {
+              const float wx = wshfl(bx[c], src);
+              if (!stop) px[pass][c] = wx;
+            }
           }
           if (!stop) {
             if (pass < 3) sel[pass] = bi;
