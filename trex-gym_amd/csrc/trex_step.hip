@@ -699,7 +699,11 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
 #pragma unroll
         for (int i = 0; i < (TL * CG_WORDS + 63) / 64; i++)
           if (lt + 64 * i < TL * CG_WORDS) z[lt + 64 * i] = 0u;
-        if (lt < TL) G.best[lt] = ~0ull;
+        if (lt < TL) {   // (the all-ones key made here, not hoisted out of the substep loop as a register pair)
+          int ones = -1;
+          asm volatile("" : "+v"(ones));
+          *reinterpret_cast<int2 *>(&G.best[lt]) = make_int2(ones, ones);
+        }
       }
       // ---- table of the near hulls: position of their first vertex in the list, ... (prefix sum over the set bits)
       int total = 0;
@@ -1815,11 +1819,19 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
 #pragma unroll
     for (int k = 0; k < 3; k++) pos[k] = uni(pos[k] + bv[k] * dt);
     {
-      const float wn = sqrtf(dot3(bw, bw)), th = wn * dt;
-      float dq[4] = {0.f, 0.f, 0.f, 1.f};
-      if (th > 1e-12f) {
-        const float sh = sinf(0.5f * th) / wn;
-        dq[0] = bw[0] * sh; dq[1] = bw[1] * sh; dq[2] = bw[2] * sh; dq[3] = cosf(0.5f * th);
+      // exponential map of w dt: dq = (w sin(h)/|w|, cos(h)), h = |w| dt / 2. Below h = 1/4 (|w| < 250 rad/s at
+      // dt = 2 ms: every physical state) the series in h^2 are exact to f32 rounding and need neither |w| nor a
+      // division: sin(h)/|w| = dt/2 (1 - h^2/6 + h^4/120 - h^6/5040 + h^8/362880)
+      const float w2 = dot3(bw, bw), h2 = 0.25f * dt * dt * w2;
+      float dq[4];
+      if (h2 < 0.0625f) {
+        const float sc = 1.f + h2 * (-1.f / 6.f + h2 * (1.f / 120.f + h2 * (-1.f / 5040.f + h2 * (1.f / 362880.f))));
+        const float sh = 0.5f * dt * sc;
+        dq[0] = bw[0] * sh; dq[1] = bw[1] * sh; dq[2] = bw[2] * sh;
+        dq[3] = 1.f + h2 * (-0.5f + h2 * (1.f / 24.f + h2 * (-1.f / 720.f + h2 * (1.f / 40320.f))));
+      } else {
+        const float wn = sqrtf(w2), sh = sinf(0.5f * wn * dt) / wn;
+        dq[0] = bw[0] * sh; dq[1] = bw[1] * sh; dq[2] = bw[2] * sh; dq[3] = cosf(0.5f * wn * dt);
       }
       float o[4];
       o[3] = dq[3] * quat[3] - dq[0] * quat[0] - dq[1] * quat[1] - dq[2] * quat[2];
