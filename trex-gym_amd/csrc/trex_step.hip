@@ -232,18 +232,24 @@ __device__ __forceinline__ void sym6_full(const Sym6 &m, float *f) {
       f[6 * (3 + r) + 3 + c] = m.C[sidx[r][c]];
     }
 }
-// M -= U U^T * s
-__device__ __forceinline__ void sym6_rank1_sub(Sym6 &m, const float *U, float s) {
+// M -= U Us^T with Us = U * s already formed: one fma per entry
+__device__ __forceinline__ void sym6_rank1_sub(Sym6 &m, const float *U, const float *Us) {
   const int ia[6] = {0, 0, 0, 1, 1, 2}, ib[6] = {0, 1, 2, 1, 2, 2};
 #pragma unroll
   for (int k = 0; k < 6; k++) {
-    m.A[k] -= U[ia[k]] * U[ib[k]] * s;
-    m.C[k] -= U[3 + ia[k]] * U[3 + ib[k]] * s;
+    m.A[k] = __builtin_fmaf(-U[ia[k]], Us[ib[k]], m.A[k]);
+    m.C[k] = __builtin_fmaf(-U[3 + ia[k]], Us[3 + ib[k]], m.C[k]);
   }
 #pragma unroll
   for (int r = 0; r < 3; r++)
 #pragma unroll
-    for (int c = 0; c < 3; c++) m.B[3 * r + c] -= U[r] * U[3 + c] * s;
+    for (int c = 0; c < 3; c++) m.B[3 * r + c] = __builtin_fmaf(-U[r], Us[3 + c], m.B[3 * r + c]);
+}
+// o += a x b, two fma per entry
+__device__ __forceinline__ void cross3_acc(const float *a, const float *b, float &o0, float &o1, float &o2) {
+  o0 = __builtin_fmaf(a[1], b[2], __builtin_fmaf(-a[2], b[1], o0));
+  o1 = __builtin_fmaf(a[2], b[0], __builtin_fmaf(-a[0], b[2], o1));
+  o2 = __builtin_fmaf(a[0], b[1], __builtin_fmaf(-a[1], b[0], o2));
 }
 
 // SPD 6x6 systems (the base's articulated inertia): Cholesky factor L kept as its 15 strictly-lower entries
@@ -1140,11 +1146,14 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
             const float rD = __builtin_amdgcn_rcpf(D);
             const float invD = rD * __builtin_fmaf(-D, rD, 2.0f);   // v_rcp_f32 + one Newton step (no IEEE division expansion)
             const float u = tau_j - dot3(Sa, pA);
+            float Ud[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) Ud[k] = U[k] * invD;
             {
               float4 *rec = &W.body[BREC * bl];
               rec[0] = make_float4(Sa[0], Sa[1], Sa[2], invD);
-              rec[2] = make_float4(U[0] * invD, U[1] * invD, U[2] * invD, U[3] * invD);
-              rec[3] = make_float4(U[4] * invD, U[5] * invD, __int_as_float(psrc + 256 * depth), u * invD);
+              rec[2] = make_float4(Ud[0], Ud[1], Ud[2], Ud[3]);
+              rec[3] = make_float4(Ud[4], Ud[5], __int_as_float(psrc + 256 * depth), u * invD);
             }
             {   // pa = pA + Ia c + U u / D with Ia c = IA c - U (U.c) / D
               float Ic[6];
@@ -1153,33 +1162,30 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
 #pragma unroll
               for (int k = 0; k < 6; k++) pA[k] += Ic[k] + U[k] * coef;
             }
-            sym6_rank1_sub(IA, U, invD);
+            sym6_rank1_sub(IA, U, Ud);
             // shift both to the parent's origin (this origin = parent origin + d, d = dpar):
             //   n' = n + d x f,  B' = B + [d]x C,  A' = A + X^T + X', X = [d]x B^T, X' = [d]x B'^T
             {
-              float t[3];
-              cross3(dpar, pA + 3, t);
-#pragma unroll
-              for (int k = 0; k < 3; k++) pA[k] += t[k];
+              cross3_acc(dpar, pA + 3, pA[0], pA[1], pA[2]);
               const int sidx[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
 #pragma unroll
-              for (int i = 0; i < 3; i++) {   // A_ij += X_ji = (d x row i of B)_j
-                cross3(dpar, IA.B + 3 * i, t);
-#pragma unroll
-                for (int j = i; j < 3; j++) IA.A[sidx[i][j]] += t[j];
+              for (int i = 0; i < 3; i++) {   // A_ij += X_ji = (d x row i of B)_j, j >= i
+                float t[3] = {0.f, 0.f, 0.f};
+                if (i == 0) cross3_acc(dpar, IA.B, IA.A[0], IA.A[1], IA.A[2]);
+                else if (i == 1) cross3_acc(dpar, IA.B + 3, t[0], IA.A[3], IA.A[4]);
+                else cross3_acc(dpar, IA.B + 6, t[0], t[1], IA.A[5]);
               }
 #pragma unroll
               for (int j = 0; j < 3; j++) {   // column j of [d]x C = d x (column j of C)
                 const float cj[3] = {IA.C[sidx[0][j]], IA.C[sidx[1][j]], IA.C[sidx[2][j]]};
-                cross3(dpar, cj, t);
-#pragma unroll
-                for (int i = 0; i < 3; i++) IA.B[3 * i + j] += t[i];
+                cross3_acc(dpar, cj, IA.B[j], IA.B[3 + j], IA.B[6 + j]);
               }
 #pragma unroll
-              for (int j = 0; j < 3; j++) {   // A_ij += X'_ij = (d x row j of B')_i
-                cross3(dpar, IA.B + 3 * j, t);
-#pragma unroll
-                for (int i = 0; i <= j; i++) IA.A[sidx[i][j]] += t[i];
+              for (int j = 0; j < 3; j++) {   // A_ij += X'_ij = (d x row j of B')_i, i <= j
+                float t[3] = {0.f, 0.f, 0.f};
+                if (j == 0) cross3_acc(dpar, IA.B, IA.A[0], t[1], t[2]);
+                else if (j == 1) cross3_acc(dpar, IA.B + 3, IA.A[1], IA.A[3], t[2]);
+                else cross3_acc(dpar, IA.B + 6, IA.A[2], IA.A[4], IA.A[5]);
               }
             }
 #pragma unroll
