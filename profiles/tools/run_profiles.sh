@@ -13,8 +13,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python ben
 bash profiles/tools/run_pmc.sh > $OUT/pmc.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $OUT/sq -- python bench.py --steps 40 --warmup 30 --no-cpu-baseline > $OUT/bench_sq.json 2> $OUT/bench_sq.err || echo "SQ pass failed"
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS --output-format csv -d $OUT/sq2 -- python bench.py --steps 40 --warmup 30 --no-cpu-baseline > $OUT/bench_sq2.json 2> $OUT/bench_sq2.err || echo "SQ2 pass failed"
-TREX_LIB=$PWD/trex-gym_amd/trex_gym/libtrex_hip_stamps.so python scripts/wave_phases.py 4096 300 2>&1 | grep -v amdgpu.ids > $OUT/wave_phases_4096.txt
-TREX_LIB=$PWD/trex-gym_amd/trex_gym/libtrex_hip_stamps.so python scripts/wave_phases.py 256 300 2>&1 | grep -v amdgpu.ids > $OUT/wave_phases_256.txt
+TREX_LIB=$PWD/trex-gym_amd/trex_gym/libtrex_hip_stamps.so python scripts/wave_phases.py 4096 1300 16 2>&1 | grep -v amdgpu.ids > $OUT/wave_phases_4096.txt
+TREX_LIB=$PWD/trex-gym_amd/trex_gym/libtrex_hip_stamps.so python scripts/wave_phases.py 256 1300 16 2>&1 | grep -v amdgpu.ids > $OUT/wave_phases_256.txt
 ./profiles/tools/row_bench > $OUT/row_bench.txt 2>&1 || true
 ./profiles/tools/census 4096 > $OUT/census.txt 2>&1 || true
 # summarise on the box (the raw traces are too big to travel), keep only gpurun_out/prof/final
