@@ -265,6 +265,13 @@ def main():
                      "mean_wave_lifetime_frac": sj.get("mean_wave_lifetime_frac"),
                      "source": "SQ_INSTS_VALU of build %s (profiles/sq_counters.json) / live kernel_ms; peak = 1024 SIMDs "
                                "x one wave64 VALU instruction per 2 cycles x 2.4 GHz" % build_id}
+        serial = None
+        if sj and headline and sj.get("build_id") == build_id and sj.get("alone_kernel_ms"):
+            # the launch can never be shorter than its slowest env running alone on a SIMD (a 256-env launch of the
+            # same build, same actions: one wave per four SIMDs)
+            serial = {"bound": "serial instruction stream of the slowest env", "floor_ms": sj["alone_kernel_ms"],
+                      "kernel_ms": kernel_ms, "frac": sj["alone_kernel_ms"] / kernel_ms,
+                      "source": "kernel_ms of `bench.py --envs-per-gpu 256` on build %s (profiles/sq_counters.json)" % build_id}
         out = {
             "metric": "env-steps/sec (whole node), trex.urdf 4096 envs per MI355X",
             "value": n_global * args.steps / dt,
@@ -296,6 +303,7 @@ def main():
                          "note": "latency/VALU-bound by construction (serial PGS); HBM fraction reported as "
                                  "BASELINE asks, roofline_issue is the bound that matters (DESIGN.md)"},
             "roofline_issue": issue,
+            "roofline_serial": serial,
             "state_mix": {"contacts_per_env_histogram_0_to_13": {"window_start": hist0, "window_end": hist1},
                           "mean_contacts": [sum(i * c for i, c in enumerate(h)) / max(1, sum(h)) for h in (hist0, hist1)]},
             "outputs_finite": finite,

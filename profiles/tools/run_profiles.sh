@@ -9,6 +9,7 @@ OUT=gpurun_out/prof
 rm -rf $OUT gpurun_out/pmc && mkdir -p $OUT
 python bench.py --steps 300 --warmup 30 > $OUT/bench_300.json 2> $OUT/bench_300.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_20.json 2> $OUT/bench_20.err
+python bench.py --steps 200 --warmup 30 --no-cpu-baseline --envs-per-gpu 256 > $OUT/bench_256.json 2> $OUT/bench_256.err   # one wave per four SIMDs: the serial floor of a launch
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --steps 200 --warmup 30 --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/bench_trace.err
 bash profiles/tools/run_pmc.sh > $OUT/pmc.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $OUT/sq -- python bench.py --steps 40 --warmup 30 --no-cpu-baseline > $OUT/bench_sq.json 2> $OUT/bench_sq.err || echo "SQ pass failed"

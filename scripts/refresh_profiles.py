@@ -85,12 +85,18 @@ S += ["", "derived:",
       "* wave cycles: waiting on counters (SQ_WAIT_ANY) %.0f %%, issue stalls (SQ_WAIT_INST_ANY) %.0f %%" % (
           100 * v.get("SQ_WAIT_ANY", 0) / v["SQ_WAVE_CYCLES"], 100 * v.get("SQ_WAIT_INST_ANY", 0) / v["SQ_WAVE_CYCLES"])]
 open("%s/%s_sq_counters.md" % (out, tag), "w").write("\n".join(S) + "\n")
-json.dump({"build_id": build, "tag": tag, "envs": 4096, "valu_insts_per_launch": v["SQ_INSTS_VALU"], "waves": w,
+alone = None
+if os.path.exists(P + "/bench_256.json"):
+    alone = json.loads([l for l in open(P + "/bench_256.json") if l.startswith("{")][-1])["roofline"]["kernel_ms"]
+    S.append("* a 256-env launch of the same build (one wave per four SIMDs: every env runs alone, the launch is its slowest env) "
+             "takes %.4f ms: no launch of any size is shorter" % alone)
+    open("%s/%s_sq_counters.md" % (out, tag), "w").write("\n".join(S) + "\n")
+json.dump({"build_id": build, "tag": tag, "envs": 4096, "valu_insts_per_launch": v["SQ_INSTS_VALU"], "waves": w, "alone_kernel_ms": alone,
            "waves_per_simd": w / 1024.0, "duration_cycles": dur, "mean_wave_lifetime_frac": life / dur,
            "valu_issue_utilisation": util, "source": "profiles/%s_sq_counters.md" % tag}, open(out + "/sq_counters.json", "w"))
 
 # ---- the rest is copied under the tag
-for src, dst in (("bench_300.json", "bench_line.json"), ("bench_20.json", "bench_line_20steps.json"), ("bench_trace.json", "bench_line_profiled.json"),
+for src, dst in (("bench_300.json", "bench_line.json"), ("bench_256.json", "bench_line_256envs.json"), ("bench_20.json", "bench_line_20steps.json"), ("bench_trace.json", "bench_line_profiled.json"),
                  ("wave_phases_4096.txt", "wave_phases_4096.txt"), ("wave_phases_256.txt", "wave_phases_256.txt"),
                  ("row_bench.txt", "row_bench.txt"), ("census.txt", "census.txt")):
     if os.path.exists(P + "/" + src):
