@@ -200,11 +200,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    hist_bins = torch.arange(16, device=dev, dtype=torch.int32).unsqueeze(0)
+
     def contact_hist():
         # stays on the device (read back after the timed region: no host round trip between pre-roll and warm-up)
+        # (and computed without torch.bincount, which reads the largest value back to size its output: a device-to-host
+        # wait of about a millisecond, after which the next ~40 launches run 3-7 % slower while the clocks come back)
         cnt = torch.zeros(n_local, dtype=torch.int32, device=dev)
         env.batch.contact_stats(cnt, None)
-        return torch.bincount(cnt.clamp(0, 15).to(torch.int64), minlength=16)
+        return (cnt.clamp(0, 15).unsqueeze(1) == hist_bins).sum(0)
 
     env.reset_tensor()
     # staggered episodes, keyed by the GLOBAL env id: env i starts i * EPISODE_STEPS / N steps into its episode, so
@@ -242,6 +246,8 @@ def main():
 
     # dominant kernel: average launch duration over the SAME timed region, from the HIP events
     kernel_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)
+    if os.environ.get("TREX_BENCH_DUMP_EVENTS") and rank == 0:   # per-launch durations of the timed region (diagnostic)
+        print("kernel ms per timed step: " + " ".join("%.4f" % a.elapsed_time(b) for a, b in events), file=sys.stderr)
     finite = bool(torch.isfinite(env.obs).all().item())
     info = env.batch.launch_info()
     build_id = _capi.build_id()
