@@ -188,11 +188,13 @@ def main():
                 events.append((e0, e1))
             if world > 1:
                 if gather_mode[0] == "pipelined":
-                    env.all_gather_rows_pipelined()   # overlaps the next step; consumer sees rows one step late
+                    # overlaps the next step; a consumer sees the rows one step late and orders ITSELF behind the
+                    # gather (none here): the compute stream only waits for the block it is about to rewrite
+                    env.all_gather_rows_pipelined(wait=False)
                 else:
                     env.all_gather_rows()             # blocking: the consumer sees this step's rows
             elif force_gather:   # one-GPU rehearsal of the collective call itself (RCCL, world of 1)
-                pipe.push(env.rows, copy=False)
+                pipe.push(env.rows, copy=False, wait=False)
 
     def fence():
         torch.cuda.synchronize()
@@ -216,21 +218,6 @@ def main():
     env.set_episode_steps(((ids * EPISODE_STEPS) // n_global).to(torch.int32))
     run(args.preroll, 0)
     t_base = args.preroll
-    blocking_ms = None
-    if world > 1:   # the blocking form of the exchange, reported beside the pipelined one (not `value`)
-        gather_mode[0] = "blocking"
-        nb = max(10, min(args.steps, 50))
-        run(5, t_base)
-        fence()
-        tb = time.perf_counter()
-        run(nb, t_base + 5)
-        fence()
-        blocking_ms = (time.perf_counter() - tb) / nb * 1e3
-        tm_ = torch.tensor([blocking_ms], device=dev, dtype=torch.float64)
-        dist.all_reduce(tm_, op=dist.ReduceOp.MAX)
-        blocking_ms = tm_.item()
-        t_base += 5 + nb
-        gather_mode[0] = "pipelined"
     hist0 = contact_hist()   # (before the warm-up: nothing but the mandatory fence sits between warm-up and timing)
     run(args.warmup, t_base)
     fence()
@@ -243,6 +230,22 @@ def main():
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
+    blocking_ms = None
+    if world > 1:   # the blocking form of the exchange, reported beside the pipelined one (not `value`); AFTER the
+        #             timed region: its fences and read-backs would slow the launches that follow them
+        gather_mode[0] = "blocking"
+        nb = max(10, min(args.steps, 50))
+        tb0 = t_base + args.warmup + args.steps
+        run(5, tb0)
+        fence()
+        tb = time.perf_counter()
+        run(nb, tb0 + 5)
+        fence()
+        blocking_ms = (time.perf_counter() - tb) / nb * 1e3
+        tm_ = torch.tensor([blocking_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(tm_, op=dist.ReduceOp.MAX)
+        blocking_ms = tm_.item()
+        gather_mode[0] = "pipelined"
 
     # dominant kernel: average launch duration over the SAME timed region, from the HIP events
     kernel_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)

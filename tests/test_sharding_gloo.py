@@ -126,7 +126,9 @@ def _pipe_worker(rank, world, port, ret, in_place=False):
         assert local.shape == (3, 5)
         if in_place:
             blocks[t & 1].copy_(local)                    # "step t" writes block t & 1 ...
-            prev = pipe.push(blocks[t & 1], copy=False)   # ... which is gathered where it lies
+            prev = pipe.push(blocks[t & 1], copy=False, wait=False)   # ... which is gathered where it lies
+            if prev is not None:
+                pipe.last_work().wait()                   # (wait=False: the consumer orders itself behind the gather)
         else:
             prev = pipe.push(local)
             local.fill_(-1.0)    # the caller may overwrite its rows at once (they were staged)

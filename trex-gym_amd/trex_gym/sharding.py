@@ -98,11 +98,14 @@ class PipelinedGather:
         self.work = [None, None]
         self.k = 0
 
-    def push(self, local, copy=True):
+    def push(self, local, copy=True, wait=True):
         """Launch the gather of `local`; returns the previous call's gathered rows (None on the first).
         copy=False: `local` is gathered in place - the caller leaves it untouched until the call after the
         next has returned (a producer that alternates between two row blocks does: TrexVecEnv(row_buffers=2)),
-        and no staging copy sits between two steps on the compute stream."""
+        and no staging copy sits between two steps on the compute stream.
+        wait=False: the returned rows are NOT yet ordered before the caller's stream (a consumer on another stream
+        orders itself behind `last_work()`); the producer's stream then carries one cross-stream wait per step - the
+        one that protects the block about to be rewritten - instead of two."""
         k = self.k
         if self.work[k] is not None:     # the collective that last read stage[k] / wrote out[k]
             self.work[k].wait()
@@ -115,8 +118,13 @@ class PipelinedGather:
         self.k = prev
         if self.work[prev] is None:
             return None
-        self.work[prev].wait()
+        if wait:
+            self.work[prev].wait()
         return self.out[prev]
+
+    def last_work(self):
+        """Work handle of the gather whose rows the last push() returned (None before the second push)."""
+        return self.work[self.k]
 
     def flush(self):
         """Wait for everything in flight; returns the most recent gathered rows."""

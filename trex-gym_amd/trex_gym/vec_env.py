@@ -126,7 +126,7 @@ class TrexVecEnv:
                                                     self.process_group, out=self._gather_buf)
         return self._gather_buf
 
-    def all_gather_rows_pipelined(self, rows=None):
+    def all_gather_rows_pipelined(self, rows=None, wait=True):
         """Like all_gather_rows, but the collective overlaps the next step: returns the rows gathered by the
         PREVIOUS call (None on the first). See sharding.PipelinedGather."""
         rows = self.rows if rows is None else rows
@@ -137,7 +137,7 @@ class TrexVecEnv:
                 raise ValueError("pipelined gather needs equal shards")
             self._pipe = sharding.PipelinedGather(self.num_envs, rows.shape[1], self.world_size, rows.dtype,
                                                   self.device, self.process_group)
-        return self._pipe.push(rows, copy=not (rows is self.rows and len(self._row_blocks) > 1))
+        return self._pipe.push(rows, copy=not (rows is self.rows and len(self._row_blocks) > 1), wait=wait)
 
     def all_gather_obs(self):
         """[global N, 3J]: the observation columns of all_gather_rows()."""
