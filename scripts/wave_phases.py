@@ -41,12 +41,13 @@ def main():
     torch.cuda.synchronize()
     cnt = torch.zeros(n, dtype=torch.int32, device=dev)
     b.contact_stats(cnt, None)
-    raw = dbg.cpu().numpy()[4096:4096 + 12 * n].reshape(12, n)
+    raw = dbg.cpu().numpy()[4096:4096 + 14 * n].reshape(14, n)
     env_of_wave = raw[11].astype(np.int64)          # the launch is balanced like the product's: wave k runs env perm[k]
     c = cnt.cpu().numpy()[env_of_wave]              # contacts of the env each wave ran
     d = raw[:9].copy()
-    sub = raw[9:11]                      # contact generation split: [small-hull scan, large-hull scan]; d[1] = the rest
-    d[1] += sub.sum(0)
+    sub = raw[9:11]                      # contact generation split: [broad phase + table, scan]; d[1] = the rest
+    sel = raw[12:14] if raw.shape[0] >= 14 else np.zeros((2, n))   # [deepest vertices + set-up, fill + passes] (K >= 2 path)
+    d[1] += sub.sum(0) + sel.sum(0)
     tot = d.sum(0)
     print("waves %d, contacts per env mean %.2f max %d" % (n, c.mean(), c.max()))
     print("wave cycles: mean %.3g  median %.3g  p90 %.3g  p99 %.3g  max %.3g  (max/mean %.2f)" % (
@@ -55,8 +56,9 @@ def main():
     print("%-36s %12s %7s %14s" % ("phase", "mean cycles", "share", "slowest 1 %"))
     for k, name in enumerate(NAMES):
         print("%-36s %12.0f %6.1f %% %14.0f" % (name, d[k].mean(), 100 * d[k].mean() / tot.mean(), d[k][slow].mean()))
-    print("contact generation = broad phase + small-hull scan %.0f + large-hull scan %.0f + point selection %.0f (slowest 1 %%: %.0f + %.0f + %.0f)" % (
-        sub[0].mean(), sub[1].mean(), (d[1] - sub.sum(0)).mean(), sub[0][slow].mean(), sub[1][slow].mean(), (d[1] - sub.sum(0))[slow].mean()))
+    rest = d[1] - sub.sum(0) - sel.sum(0)
+    print("contact generation = broad phase + table %.0f + scan %.0f + deepest vertices, ranking, set-up %.0f + candidate fill, passes %.0f + output %.0f" % (
+        sub[0].mean(), sub[1].mean(), sel[0].mean(), sel[1].mean(), rest.mean()))
     for lo_, hi_ in ((0, 0), (1, 4), (5, 8), (9, 13)):
         sel = (c >= lo_) & (c <= hi_)
         if sel.any():

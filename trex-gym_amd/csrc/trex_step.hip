@@ -843,6 +843,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
         // keeps the positions for all passes: one trip to L2 per substep instead of one per pass, no vertex placed
         // twice. If any lane holds more (or a body is beyond the mask capacity) the passes re-read, as before.
         constexpr int CC = 4;
+        SUBSTAMP(12);   // deepest vertices, ranking, group set-up
         const bool cached = __ballot(act && (!masked || __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3) > CC)) == 0ull;
         float cx[CC][3];
         int cvx[CC];
@@ -954,6 +955,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
             nsel = pass + 1;
           }
         }
+        SUBSTAMP(13);   // candidate fill and the selection passes
         // the points go out in body order (= group order), the deepest vertex of a body first
         int off = 0;
         for (int i = 0; i < n_active; i++) {
