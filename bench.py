@@ -172,20 +172,18 @@ def main():
     pool = torch.stack([sharding.synthetic_actions(ids, t, mid - half, mid + half, seed=0, device=dev) for t in range(16)])
     if args.action_scale != 1.0:
         overrides = dict(overrides, action_scale=args.action_scale)
-    events = []
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     force_gather = under_launcher and world == 1 and bool(os.environ.get("TREX_BENCH_FORCE_GATHER"))
     pipe = (sharding.PipelinedGather(env.num_envs, env.rows.shape[1], 1, env.rows.dtype, dev) if force_gather else None)
     gather_mode = ["pipelined"]
 
     def run(n_steps, t_base, timed=False):
         for t in range(n_steps):
-            if timed:  # HIP events on the stream the kernel is launched on (torch's current stream)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
+            if timed:  # HIP events (created before the clock starts) on the stream the kernel is launched on
+                events[t][0].record()
             env.step_tensor(pool[(t_base + t) % 16])
             if timed:
-                e1.record()
-                events.append((e0, e1))
+                events[t][1].record()
             if world > 1:
                 if gather_mode[0] == "pipelined":
                     # overlaps the next step; a consumer sees the rows one step late and orders ITSELF behind the
