@@ -18,6 +18,8 @@ __global__ __launch_bounds__(64) void k(float *out, long long *cyc, int sweeps, 
   for (int j = 0; j < NR; j++) B[j] = (tid == j + 1) ? -1.f : 1e-3f * (float)((tid * 7 + j * 13) % 11 - 5);
   float y = 0.01f * (tid + 1), lam = 0.f, blo = -hi, bhi = hi;
   int dv = 0, sprev = 0, scur = 0;
+  __shared__ float cap[NR * 64];
+  const int lds_addr = (int)(size_t)(void *)cap * 0 + 4 * tid;   // (offset inside the workgroup's LDS)
   float bsub = 1e-3f * (float)(tid % 5 - 2);
   float scratchv = 0.f;
   const long long t0 = __builtin_amdgcn_s_memtime();
@@ -27,6 +29,7 @@ __global__ __launch_bounds__(64) void k(float *out, long long *cyc, int sweeps, 
     asm volatile("" : "+v"(vs));
     unsigned long long one = 1ull;
     asm volatile("" : "+s"(one));
+    if (VARIANT == 15) { asm volatile("s_waitcnt lgkmcnt(0)"); dv ^= __float_as_int(cap[65 * (tid & 31)]); }   // the diagonal, once per sweep
 #pragma unroll
     for (int j = 0; j < NR; j++) {
       const int L = j + 1;
@@ -93,6 +96,16 @@ __global__ __launch_bounds__(64) void k(float *out, long long *cyc, int sweeps, 
           asm volatile("v_add_f32_e32 %2, %8, %0\n\tv_med3_f32 %2, %2, %4, %5\n\tv_sub_f32_e32 %2, %2, %8\n\tv_writelane_b32 %1, %3, %7\n\tv_readlane_b32 %3, %2, %7\n\ts_nop 1\n\tv_fmac_f32_e32 %0, %3, %6"
                        : "+v"(y), "+v"(dv), "=&v"(d_), "+s"(sprev) : "v"(blo), "v"(bhi), "v"(B[j]), "n"(1 + (j % 63)), "v"(lam));
         (void)s_;
+      } else if (VARIANT == 15) {
+        // capture through LDS: every lane stores its d at [row][lane] (the diagonal is read back once per sweep),
+        // the store is the wait state between v_med3 and v_readlane - an LDS instruction instead of a VALU one
+        float d_;
+        asm volatile("v_med3_f32 %1, %0, %3, %4\n\t"
+                     "ds_write_b32 %6, %1 offset:%8\n\t"
+                     "v_readlane_b32 %2, %1, %7\n\t"
+                     "s_nop 1\n\t"
+                     "v_fmac_f32_e32 %0, %2, %5"
+                     : "+v"(y), "=&v"(d_), "+s"(sprev) : "v"(blo), "v"(bhi), "v"(B[j]), "v"(lds_addr), "n"(1 + (j % 63)), "n"(256 * j));
       } else if (VARIANT == 13 || VARIANT == 14) {
         // neighbour fast path: the next row's lane gets this row's change by DPP (wave_shr:1, VGPR to VGPR), the other
         // lanes by the SGPR broadcast ONE ROW LATER (software-pipelined: no s_nop, the readlane round trip is off the
@@ -160,5 +173,6 @@ int main() {
   run<11>("11 asm, 6 slots, two v_mov for s_nop 1", out, cyc, sweeps);
   run<13>("13 neighbour DPP fast path, pipelined broadcast", out, cyc, sweeps);
   run<14>("14 the same without the capture", out, cyc, sweeps);
+  run<15>("15 capture by ds_write_b32 [row][lane]", out, cyc, sweeps);
   return 0;
 }
