@@ -1512,51 +1512,53 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
   }
 // A point with no normal impulse before its visit (lam_n = 0) and none after it (lam_n + y_n <= 0) changes
 // nothing: its normal row gives d = 0, its friction rows are clamped to 0 and hold 0 already (they were visited
-// after the normal row lost its impulse). Under random actions 9 in 10 candidate points are like that - inside the
-// 2 cm margin, not pressing. ONE vector test over all normal-row lanes (`alive_points`) therefore precedes the point
-// blocks: a dead point costs a scalar bit test, and the test is repeated after every point that was processed
-// (it changed y). Bitwise the same result as visiting every row: the skipped updates would add B * 0.
+// after the normal row lost its impulse). Most candidate points are like that - inside the 2 cm margin, not
+// pressing. ONE vector test over all normal-row lanes (`alive_points`) therefore precedes the point blocks: a dead
+// point costs a scalar bit test, and the test is repeated after every point that was processed (it changed y).
+// Bitwise the same result as visiting every row: the skipped updates would add B * 0.
+// A live point is one hand-placed block of 28 slots. Like the motor rows, its rows work with bounds SHIFTED by the
+// impulse: normal d = max(y, -lam) (one instruction; lam + d = 0 exactly when the contact lets go), friction
+// d = med3(y, -hi - lam, hi - lam) with hi = mu * the new normal impulse, the two shifted bounds formed once for
+// both friction lanes; the three changes are captured by v_writelane - which doubles as the wait state between a
+// v_med3 and the v_readlane of its result - and committed with one add.
 #define TREX_POINT_TEXT(P)                                                                             \
                "s_bitcmp1_b64 %[al], %[ln" #P "]\n\t"                                                  \
                "s_cbranch_scc0 " #P "f\n\t"                                                            \
-               /* normal row: nl = max(lam + y, 0) */                                                  \
-               "v_add_f32_e32 %[t], %[lam], %[y]\n\t"                                                  \
-               "v_max_f32_e32 %[t], 0, %[t]\n\t"                                                       \
-               "v_sub_f32_e32 %[d], %[t], %[lam]\n\t"                                                  \
-               "v_readlane_b32 %[snl], %[t], %[ln" #P "]\n\t"                                          \
+               /* normal row, bounds shifted by the impulse: d = max(y, -lam); the new impulse lam + d */ \
+               "v_max_f32_e64 %[d], %[y], -%[lam]\n\t"                                                 \
+               "v_add_f32_e32 %[t], %[lam], %[d]\n\t"                                                  \
                "v_readlane_b32 %[sd], %[d], %[ln" #P "]\n\t"                                           \
-               "v_cmp_eq_u32_e32 vcc, %[ln" #P "], %[vs]\n\t"                                          \
-               "v_mul_f32_e32 %[hi], %[snl], %[mu]\n\t"                                                \
+               "v_readlane_b32 %[snl], %[t], %[ln" #P "]\n\t"                                          \
+               "v_mov_b32_e32 %[dv], 0\n\t"                /* the point's three impulse changes are captured here */ \
                "v_fmac_f32_e32 %[y], %[sd], %[b0" #P "]\n\t"                                           \
-               "v_cndmask_b32_e32 %[lam], %[lam], %[t], vcc\n\t"                                       \
-               /* friction x: nl = med3(lam + y, -hi, hi) */                                           \
-               "v_cmp_eq_u32_e32 vcc, %[lx" #P "], %[vs]\n\t"                                          \
-               "v_add_f32_e32 %[t], %[lam], %[y]\n\t"                                                  \
-               "v_med3_f32 %[t], %[t], -%[hi], %[hi]\n\t"                                              \
-               "v_sub_f32_e32 %[d], %[t], %[lam]\n\t"                                                  \
-               "v_cndmask_b32_e32 %[lam], %[lam], %[t], vcc\n\t"                                       \
-               "v_readlane_b32 %[sd], %[d], %[lx" #P "]\n\t"                                           \
-               "v_cmp_eq_u32_e32 vcc, %[ly" #P "], %[vs]\n\t"                                          \
-               "s_nop 0\n\t"                                                                           \
-               "v_fmac_f32_e32 %[y], %[sd], %[b1" #P "]\n\t"                                           \
+               "v_mul_f32_e32 %[hi], %[snl], %[mu]\n\t"                                                \
+               /* friction bounds -hi - lam, hi - lam for both friction lanes at once */               \
+               "v_sub_f32_e64 %[t], -%[hi], %[lam]\n\t"                                                \
+               "v_sub_f32_e32 %[hi], %[hi], %[lam]\n\t"                                                \
+               /* friction x */                                                                        \
+               "v_med3_f32 %[d], %[y], %[t], %[hi]\n\t"                                                \
+               "v_writelane_b32 %[dv], %[sd], %[ln" #P "]\n\t"                                         \
+               "v_readlane_b32 %[snl], %[d], %[lx" #P "]\n\t"                                          \
+               "s_nop 1\n\t"                                                                           \
+               "v_fmac_f32_e32 %[y], %[snl], %[b1" #P "]\n\t"                                          \
                /* friction y */                                                                        \
-               "v_add_f32_e32 %[t], %[lam], %[y]\n\t"                                                  \
-               "v_med3_f32 %[t], %[t], -%[hi], %[hi]\n\t"                                              \
-               "v_sub_f32_e32 %[d], %[t], %[lam]\n\t"                                                  \
-               "v_cndmask_b32_e32 %[lam], %[lam], %[t], vcc\n\t"                                       \
+               "v_med3_f32 %[d], %[y], %[t], %[hi]\n\t"                                                \
+               "v_writelane_b32 %[dv], %[snl], %[lx" #P "]\n\t"                                        \
                "v_readlane_b32 %[sd], %[d], %[ly" #P "]\n\t"                                           \
-               "v_cmp_neq_f32_e64 %[tmp], 0, %[lam]\n\t"                                               \
-               "s_nop 0\n\t"                                                                           \
+               "s_nop 1\n\t"                                                                           \
                "v_fmac_f32_e32 %[y], %[sd], %[b2" #P "]\n\t"                                           \
-               /* which points can change anything now */                                              \
+               "v_writelane_b32 %[dv], %[sd], %[ly" #P "]\n\t"                                         \
+               /* commit, and which points can change anything now */                                  \
+               "v_add_f32_e32 %[lam], %[lam], %[dv]\n\t"                                               \
                "v_add_f32_e32 %[t], %[lam], %[y]\n\t"                                                  \
+               "v_cmp_neq_f32_e64 %[tmp], 0, %[lam]\n\t"                                               \
                "v_cmp_lt_f32_e32 vcc, 0, %[t]\n\t"                                                     \
                "s_or_b64 %[al], vcc, %[tmp]\n\t"                                                       \
                "s_and_b64 %[al], %[al], %[nrm]\n\t"                                                    \
                #P ":\n\t"
 #define TREX_POINT_OUTS [y] "+v"(y), [lam] "+v"(lam), [al] "+s"(alive), [t] "=&v"(pt_), [d] "=&v"(pd_), [hi] "=&v"(ph_), \
-                        [snl] "=&s"(psn_), [sd] "=&s"(psd_), [tmp] "=&s"(ptm_)
-#define TREX_POINT_INS [vs] "v"(vs), [mu] "v"(mu), [nrm] "s"(nrm_mask)
+                        [dv] "=&v"(pv_), [snl] "=&s"(psn_), [sd] "=&s"(psd_), [tmp] "=&s"(ptm_)
+#define TREX_POINT_INS [mu] "v"(mu), [nrm] "s"(nrm_mask)
 #define TREX_POINT_OPS(P, S) [b0##P] "v"(Bc[3 * (S)]), [b1##P] "v"(Bc[3 * (S) + 1]), [b2##P] "v"(Bc[3 * (S) + 2]),     \
                              [ln##P] "n"(KROW_LANE(3 * (S))), [lx##P] "n"(KROW_LANE(3 * (S) + 1)), [ly##P] "n"(KROW_LANE(3 * (S) + 2))
 // (several point slots per asm statement: the compiler closes every statement with an s_nop of its own)
@@ -1575,14 +1577,13 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
 #endif
 #pragma unroll 1
       for (int it = 0; it < iters; it++) {
-        // the lane id, opaque once per sweep: `vs == j` is then one v_cmp where it is used, not a mask hoisted out
-        // of the loop and spilled. (A lane mask built on the scalar unit - s_lshl_b64 + v_cndmask - measured
-        // SLOWER than v_cmp + v_cndmask: 17.6 against 15.2 cycles per row and SIMD at 4 waves per SIMD,
-        // profiles/tools/row_bench.hip.)
-        int vs = lt;
-        asm volatile("" : "+v"(vs));
         // limit rows: the row of joint j rides on motor lane j, whose y gives dv_j / diag = rhs - y
         for (unsigned m = lim_mask; m != 0u; m &= m - 1u) {
+          // the lane id, opaque: `vs == j` is then one v_cmp here, not a mask hoisted out of the loops and spilled.
+          // (A lane mask built on the scalar unit - s_lshl_b64 + v_cndmask - measured SLOWER than v_cmp +
+          // v_cndmask: 17.6 against 15.2 cycles per row and SIMD at 4 waves per SIMD, profiles/tools/row_bench.hip.)
+          int vs = lt;
+          asm volatile("" : "+v"(vs));
           const int j = __ffs(m) - 1;
           const float nl = fmaxf(lim_lam + (lr + ldir * y), 0.f);
           const float dl = (nl - lim_lam) * ldir;
@@ -1747,7 +1748,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
         // the live point slots, in order (dead slots have no bit in `alive`)
         unsigned long long alive = nrm_mask != 0ull ? alive_points() : 0ull;   // (an airborne env has no point rows at all)
         if (alive != 0ull) {
-          float pt_, pd_, ph_;
+          float pt_, pd_, ph_, pv_;
           int psn_, psd_;
           unsigned long long ptm_;
           if (s0 < 7) { TREX_POINTS3(0) TREX_POINTS3(3) TREX_POINTS1(6) }
