@@ -1516,7 +1516,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
 // pressing. ONE vector test over all normal-row lanes (`alive_points`) therefore precedes the point blocks: a dead
 // point costs a scalar bit test, and the test is repeated after every point that was processed (it changed y).
 // Bitwise the same result as visiting every row: the skipped updates would add B * 0.
-// A live point is one hand-placed block of 28 slots. Like the motor rows, its rows work with bounds SHIFTED by the
+// A live point is one hand-placed block of 27 slots. Like the motor rows, its rows work with bounds SHIFTED by the
 // impulse: normal d = max(y, -lam) (one instruction; lam + d = 0 exactly when the contact lets go), friction
 // d = med3(y, -hi - lam, hi - lam) with hi = mu * the new normal impulse, the two shifted bounds formed once for
 // both friction lanes; the three changes are captured by v_writelane - which doubles as the wait state between a
@@ -1550,9 +1550,8 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
                "v_writelane_b32 %[dv], %[sd], %[ly" #P "]\n\t"                                         \
                /* commit, and which points can change anything now */                                  \
                "v_add_f32_e32 %[lam], %[lam], %[dv]\n\t"                                               \
-               "v_add_f32_e32 %[t], %[lam], %[y]\n\t"                                                  \
                "v_cmp_neq_f32_e64 %[tmp], 0, %[lam]\n\t"                                               \
-               "v_cmp_lt_f32_e32 vcc, 0, %[t]\n\t"                                                     \
+               "v_cmp_gt_f32_e64 vcc, %[y], -%[lam]\n\t"               /* lam + y > 0 */              \
                "s_or_b64 %[al], vcc, %[tmp]\n\t"                                                       \
                "s_and_b64 %[al], %[al], %[nrm]\n\t"                                                    \
                #P ":\n\t"
@@ -1571,7 +1570,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
   asm volatile(TREX_POINT_TEXT(0) : TREX_POINT_OUTS : TREX_POINT_INS, TREX_POINT_OPS(0, S) : "vcc", "scc");
       // lanes that hold the normal row of a live point slot
       const unsigned long long nrm_mask = __ballot(lt >= CLANE0 && (lt - CLANE0) % 3 == 0 && (lt - CLANE0) / 3 >= s0);
-      auto alive_points = [&]() { return nrm_mask & (__ballot(lam != 0.f) | __ballot(lam + y > 0.f)); };   // (two v_cmp + s_or)
+      auto alive_points = [&]() { return nrm_mask & (__ballot(lam != 0.f) | __ballot(y > -lam)); };   // (two v_cmp + s_or)
 #if TREX_PRIO_MODE == 1
       set_sweep_priority(nc);
 #endif
