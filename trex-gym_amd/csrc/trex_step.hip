@@ -25,9 +25,12 @@
 //     DISTRIBUTED. Every constraint row walks ITS OWN chain once, on its own lane (motor rows and
 //     contact rows in the same pass, reading the body records), and keeps a descriptor (chain nodes,
 //     entries u, u/D, base force r0, I0^-1 r0); any entry of the Delassus matrix J M^-1 J^T is then 12
-//     multiply-adds of two descriptors, the column's one broadcast with v_readlane.
+//     multiply-adds of two descriptors, the column's one read from LDS at one address by all lanes.
 //   * projected Gauss-Seidel runs in Delassus (residual) form: a row's impulse change reaches all other
-//     rows as one v_readlane (SGPR broadcast) + one FMA per lane - no reduction, no LDS in a row.
+//     rows as one v_readlane (SGPR broadcast) + one FMA per lane - no reduction, no LDS in a row. The rows are
+//     hand-placed: 5 issue slots per motor row, 27 per live contact point (bounds shifted by the impulse).
+//   * which wave runs which env, and at which issue priority, is decided inside the kernel (contact counts of the
+//     previous launch; the SIMD's arbiter breaks ties by wave age, which has to be countered): set_sweep_priority.
 //   * HBM traffic per env-step is the state row in/out + action in + obs/reward out (912 B); the
 //     kernel is bound by VALU issue, not by bandwidth.
 //
