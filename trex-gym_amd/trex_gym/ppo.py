@@ -91,6 +91,7 @@ class PPO:
         self.b_rew = torch.empty(T, n, device=self.dev)
         self.b_done = torch.empty(T, n, device=self.dev)
         self.b_adv = torch.empty(T, n, device=self.dev)
+        self.b_ret = torch.empty(T, n, device=self.dev)
         self.raw_rew = torch.zeros((), device=self.dev, dtype=torch.float64)
 
     # VecNormalize (trex_train.py:45)
@@ -151,8 +152,8 @@ class PPO:
             self._rollout()
         self.total_env_steps += T * n
         flat = lambda x: x.reshape(T * n, *x.shape[2:])
-        ret = self.b_adv + self.b_val[:T]
-        return (flat(self.b_obs), flat(self.b_act), flat(self.b_logp), flat(self.b_val[:T]), flat(self.b_adv), flat(ret),
+        torch.add(self.b_adv, self.b_val[:T], out=self.b_ret)   # (a persistent buffer: the captured update reads it in place)
+        return (flat(self.b_obs), flat(self.b_act), flat(self.b_logp), flat(self.b_val[:T]), flat(self.b_adv), flat(self.b_ret),
                 (self.raw_rew / T).item())
 
     def _minibatch_step(self, obs, act, logp0, val0, adv, ret):
@@ -172,47 +173,55 @@ class PPO:
         self.opt.step()
         return pg.detach(), vf.detach(), ent.detach()
 
+    def _epoch(self, srcs, N, mb):
+        """One epoch: a fresh permutation, nminibatches optimiser steps; returns the summed (pg, vf, ent)."""
+        perm = torch.rand(N, device=self.dev).argsort()     # (capturable: no host round trip, unlike randperm's size logic)
+        acc = torch.zeros(3, device=self.dev)
+        for k in range(self.nminibatches):
+            idx = perm[k * mb:(k + 1) * mb]
+            out = self._minibatch_step(*[x.index_select(0, idx) for x in srcs])
+            acc = acc + torch.stack(out)
+        return acc
+
     def update(self, batch):
         obs, act, logp0, val0, adv, ret, _ = batch
+        srcs = (obs, act, logp0, val0, adv, ret)
         N = obs.shape[0]
         mb = N // self.nminibatches
-        if self.use_graphs and self._update_graph is None:
-            # static minibatch buffers + one captured optimiser step (warm-up on a side stream first)
-            self._mb = [torch.empty((mb,) + tuple(x.shape[1:]), device=self.dev) for x in (obs, act, logp0, val0, adv, ret)]
-            for x, src in zip(self._mb, (obs, act, logp0, val0, adv, ret)):
-                x.copy_(src[:mb])
-            keep = [p.detach().clone() for p in self.policy.parameters()]
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    self._minibatch_step(*self._mb)
-            torch.cuda.current_stream().wait_stream(side)
-            with torch.no_grad():                 # undo the warm-up: same parameters and a fresh Adam state
-                for p, k in zip(self.policy.parameters(), keep):
-                    p.copy_(k)
-                for st in self.opt.state.values():
-                    for v in st.values():
-                        if torch.is_tensor(v):
-                            v.zero_()
-            torch.cuda.synchronize()
-            self._update_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._update_graph):
-                self._mb_out = self._minibatch_step(*self._mb)
-        stats = []
-        for _ in range(self.noptepochs):
-            perm = torch.randperm(N, device=self.dev)
-            for k in range(self.nminibatches):
-                idx = perm[k * mb:(k + 1) * mb]
-                if self.use_graphs:
-                    for x, src in zip(self._mb, (obs, act, logp0, val0, adv, ret)):
-                        torch.index_select(src, 0, idx, out=x)
-                    self._update_graph.replay()
-                    out = self._mb_out
-                else:
-                    out = self._minibatch_step(obs[idx], act[idx], logp0[idx], val0[idx], adv[idx], ret[idx])
-            stats.append(tuple(o.clone() for o in out))
-        pg, vf, ent = (torch.stack(x).mean().item() for x in zip(*stats))
+        if self.use_graphs:
+            # ONE graph per epoch (a permutation + all its minibatch steps, about 2000 nodes): replaying a graph per
+            # minibatch left the update launch-bound - the 60 small kernels of a step take a third of its replay
+            if self._update_graph is None:
+                self._srcs = srcs              # views of the persistent rollout buffers: same addresses every iteration
+                keep = [p.detach().clone() for p in self.policy.parameters()]
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):      # warm-up outside the capture (library set-up, autograd buffers)
+                    for _ in range(3):
+                        self._minibatch_step(*[x[:mb] for x in srcs])
+                    torch.rand(N, device=self.dev).argsort()
+                torch.cuda.current_stream().wait_stream(side)
+                with torch.no_grad():              # undo the warm-up: same parameters and a fresh Adam state
+                    for p, k in zip(self.policy.parameters(), keep):
+                        p.copy_(k)
+                    for st in self.opt.state.values():
+                        for v in st.values():
+                            if torch.is_tensor(v):
+                                v.zero_()
+                torch.cuda.synchronize()
+                self._update_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._update_graph):
+                    self._epoch_out = self._epoch(srcs, N, mb)
+            assert all(a.data_ptr() == b.data_ptr() for a, b in zip(srcs, self._srcs)), "rollout buffers moved"
+            total = torch.zeros(3, device=self.dev)
+            for _ in range(self.noptepochs):
+                self._update_graph.replay()
+                total += self._epoch_out
+        else:
+            total = torch.zeros(3, device=self.dev)
+            for _ in range(self.noptepochs):
+                total += self._epoch(srcs, N, mb)
+        pg, vf, ent = (total / (self.noptepochs * self.nminibatches)).tolist()
         return dict(policy_loss=pg, value_loss=vf, entropy=ent)
 
     def learn(self, total_timesteps, log=print):
