@@ -37,6 +37,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # (MI355X_MICROARCH.md, chip parameters + "v_fma_f32 (wave64) 2 cyc")
 VALU_ISSUE_PEAK_GIPS = 256 * 4 * 2.4 / 2.0   # 1228.8 G wave-instructions/s
 EPISODE_STEPS = 1000   # harness time limit (the reference never terminates, trex_env.py:183-184)
+EVENT_STRIDE = 4         # HIP-event pairs around every 4th launch of the timed region (see run())
 
 
 def _cpu_worker(args):
@@ -172,18 +173,25 @@ def main():
     pool = torch.stack([sharding.synthetic_actions(ids, t, mid - half, mid + half, seed=0, device=dev) for t in range(16)])
     if args.action_scale != 1.0:
         overrides = dict(overrides, action_scale=args.action_scale)
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    stride = EVENT_STRIDE if args.steps >= EVENT_STRIDE else 1
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps // stride + 1)]
+    sampled = []
     force_gather = under_launcher and world == 1 and bool(os.environ.get("TREX_BENCH_FORCE_GATHER"))
     pipe = (sharding.PipelinedGather(env.num_envs, env.rows.shape[1], 1, env.rows.dtype, dev) if force_gather else None)
     gather_mode = ["pipelined"]
 
     def run(n_steps, t_base, timed=False):
         for t in range(n_steps):
-            if timed:  # HIP events (created before the clock starts) on the stream the kernel is launched on
-                events[t][0].record()
+            # HIP events (created before the clock starts) on the stream the kernel is launched on, around every
+            # EVENT_STRIDE-th launch of the timed region: a timing event costs the stream about 4 us, two around EVERY
+            # launch took 2.4 % off `value` (scripts/overlap_probe.py runs the same loop without events)
+            ev = events[t // stride] if (timed and t % stride == stride // 2) else None
+            if ev:
+                ev[0].record()
             env.step_tensor(pool[(t_base + t) % 16])
-            if timed:
-                events[t][1].record()
+            if ev:
+                ev[1].record()
+                sampled.append(ev)
             if world > 1:
                 if gather_mode[0] == "pipelined":
                     # overlaps the next step; a consumer sees the rows one step late and orders ITSELF behind the
@@ -246,9 +254,9 @@ def main():
         gather_mode[0] = "pipelined"
 
     # dominant kernel: average launch duration over the SAME timed region, from the HIP events
-    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)
+    kernel_ms = sum(a.elapsed_time(b) for a, b in sampled) / len(sampled)
     if os.environ.get("TREX_BENCH_DUMP_EVENTS") and rank == 0:   # per-launch durations of the timed region (diagnostic)
-        print("kernel ms per timed step: " + " ".join("%.4f" % a.elapsed_time(b) for a, b in events), file=sys.stderr)
+        print("kernel ms per sampled timed step: " + " ".join("%.4f" % a.elapsed_time(b) for a, b in sampled), file=sys.stderr)
     finite = bool(torch.isfinite(env.obs).all().item())
     info = env.batch.launch_info()
     build_id = _capi.build_id()
@@ -305,7 +313,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": "trex_step_kernel<false, false>", "kernel_ms": kernel_ms,
                          "kernel_ms_covers": "one step launch = ONE kernel, trex_step_kernel<false, false> (it ranks the envs for the next launch and "
-                                             "resets the envs whose episode ends), bracketed by HIP events",
+                                             "resets the envs whose episode ends), bracketed by HIP events; every %d-th launch of the timed region is bracketed (%d samples)" % (stride, len(sampled)),
                          "alg_bytes_per_launch": alg, "kernel_build": build_id,
                          "note": "latency/VALU-bound by construction (serial PGS); HBM fraction reported as "
                                  "BASELINE asks, roofline_issue is the bound that matters (DESIGN.md)"},
