@@ -4,6 +4,10 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--envs-per-gpu E]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both forms work for N > 1: without a launcher the parent process - before it touches torch.cuda or the HIP library -
+starts one rank process per GPU itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1),
+relays rank 0's JSON line and exits non-zero if any rank does.
+
 A "step" is one TrexBulletEnv.step() of every env: ONE launch of the fused HIP kernel
 (5 substeps x 60 solver iterations, trex_env.py:71-73). Workload at N=1 = BASELINE config 2:
 4096 envs, trex.urdf, uniform random actions in the joint limits, inputs resident in HBM.
@@ -75,7 +79,7 @@ def _cpu_worker(args):
 
 def cpu_baseline(budget_s=10.0):
     import multiprocessing as mp
-    cores = min(len(os.sched_getaffinity(0)), 16)
+    cores = len(os.sched_getaffinity(0))      # P = the affinity count, uncapped
     ctx = mp.get_context("spawn")
     with ctx.Pool(cores) as pool:
         one = pool.map(_cpu_worker, [(0, 0.0, "config1")])[0]                       # (i) single core
@@ -88,7 +92,15 @@ def cpu_baseline(budget_s=10.0):
         pb = "importable (not used: the build's generated URDF cross-check is a later row)"
     except Exception:  # noqa: BLE001
         pb = "unavailable on this host"
-    return {"value": total / wall, "unit": "env-steps/s", "cores": cores, "kind": "port",
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": total / wall, "unit": "env-steps/s", "cores": cores, "cpu_model": cpu_model, "kind": "port",
             "sample": "f64 C oracle (oracle/trex_oracle.c), %d processes x 1 env, reset + uniform random "
                       "actions for %.0f s each (%d env-steps total)" % (cores, budget_s, total),
             "config1_zero_action": {
@@ -96,6 +108,50 @@ def cpu_baseline(budget_s=10.0):
                 "single_core_env_steps_per_s": one[0] / one[1],
                 "all_cores_env_steps_per_s": cores * 1000 / max(t for _, t in many), "processes": cores},
             "pybullet": pb}
+
+
+def _self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: one rank process per GPU, started HERE - this process has made
+    no GPU call (no torch.cuda, no libtrex_hip.so) and makes none. Rank 0's stdout (the JSON line) is relayed; the
+    other ranks' stdout goes to stderr. If a rank fails the others are ended (by their own pids) and the exit code
+    is non-zero."""
+    import socket
+    import subprocess
+    import tempfile
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    out0 = tempfile.TemporaryFile()
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TREX_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=out0 if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is not None:
+                    pending.discard(r)
+                    if code != 0 and rc == 0:
+                        rc = code if code > 0 else 1
+                        print("bench.py: rank %d exited with code %d; ending the other ranks" % (r, code), file=sys.stderr)
+                        for q in pending:
+                            procs[q].terminate()
+            if pending:
+                time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
+    sys.stdout.flush()
+    sys.exit(rc)
 
 
 def _load_json(name):
@@ -111,6 +167,9 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--preroll", type=int, default=EPISODE_STEPS,
                     help="untimed steps before the warm-up that stagger the episode phases (default: one episode)")
+    ap.add_argument("--action-cycle", type=int, default=0,
+                    help="0 (default, SURVEY 8d): a FRESH uniform draw for every env and every pre-roll / warm-up / timed step, "
+                         "pre-generated into one [T, n, 25] tensor in HBM; C > 0: rounds 1-2's input, C draws per env, cycled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--collision", choices=["hulls", "primitives"], default="hulls",
                     help="primitives: capsules/spheres fitted to the hulls (148 points instead of 2181 vertices); not the headline config")
@@ -126,9 +185,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
+        if "RANK" not in os.environ and args.gpus > 1:
+            _self_launch(args.gpus, sys.argv[1:])     # never returns; nothing GPU-related has been imported yet
         args.gpus = world
 
     cpu = None
@@ -170,7 +228,13 @@ def main():
     lo, hi = env.model.lower, env.model.upper
     ids = torch.arange(env.env_lo, env.env_hi, device=dev)
     mid, half = 0.5 * (lo + hi), 0.5 * (hi - lo) * args.action_scale
-    pool = torch.stack([sharding.synthetic_actions(ids, t, mid - half, mid + half, seed=0, device=dev) for t in range(16)])
+    # a[n, j] ~ U(low_j, high_j), keyed by (seed 0, GLOBAL env id, step), a fresh draw for every step
+    # of the run, pre-generated on the device: [T, n, 25] f32 (553 MB at T = 1350, n = 4096)
+    n_blocking = max(10, min(args.steps, 50)) + 5 if world > 1 else 0
+    n_draws = args.action_cycle if args.action_cycle > 0 else args.preroll + args.warmup + args.steps + n_blocking
+    pool = torch.empty(n_draws, n_local, len(lo), device=dev)
+    for t in range(n_draws):
+        pool[t] = sharding.synthetic_actions(ids, t, mid - half, mid + half, seed=0, device=dev)
     if args.action_scale != 1.0:
         overrides = dict(overrides, action_scale=args.action_scale)
     stride = EVENT_STRIDE if args.steps >= EVENT_STRIDE else 1
@@ -188,7 +252,7 @@ def main():
             ev = events[t // stride] if (timed and t % stride == stride // 2) else None
             if ev:
                 ev[0].record()
-            env.step_tensor(pool[(t_base + t) % 16])
+            env.step_tensor(pool[(t_base + t) % n_draws])
             if ev:
                 ev[1].record()
                 sampled.append(ev)
@@ -264,7 +328,7 @@ def main():
         alg = (info["alg_bytes_per_env_step"] + (1044 if args.domain_rand else 0)) * n_local  # bytes per launch
         achieved = alg / (kernel_ms * 1e-3) / 1e9
         # PMC-derived numbers are only quoted when they were collected on THIS kernel build and workload
-        headline = args.envs_per_gpu == 4096 and not overrides and not args.domain_rand
+        headline = args.envs_per_gpu == 4096 and not overrides and not args.domain_rand and args.action_cycle == 0
         tj, sj = _load_json("pmc_traffic.json"), _load_json("sq_counters.json")
         traffic = tj["hbm_bytes_per_launch"] if (tj and headline and tj.get("build_id") == build_id) else None
         traffic_note = ("PMC FETCH_SIZE x2 + WRITE_SIZE (MI355X_MICROARCH.md), collected on build %s by "
@@ -300,10 +364,13 @@ def main():
             "data": "synthetic",
             "rccl_ranks": rccl_ranks,
             "config": {"workload": "%d envs per GPU x %d GPU(s), trex.urdf (26 bodies, 31 dof, 2181 hull "
-                                   "vertices), uniform random actions keyed by global env id (16 pre-generated draws per env, cycled), 5 substeps x 60 "
+                                   "vertices), uniform random actions keyed by (global env id, step), %s, 5 substeps x 60 "
                                    "PGS iterations per step, episode limit %d steps with staggered phases "
                                    "(pre-roll %d untimed steps)%s"
-                                   % (args.envs_per_gpu, world, EPISODE_STEPS, args.preroll,
+                                   % (args.envs_per_gpu, world,
+                                      ("NOT the headline input: %d pre-generated draws per env, cycled" % args.action_cycle) if args.action_cycle > 0
+                                      else "a fresh draw for every step, pre-generated in HBM as [%d, %d, 25] f32" % (n_draws, n_local),
+                                      EPISODE_STEPS, args.preroll,
                                       ", [obs|reward|done] all-gather over RCCL each step, overlapped with the next step (gathered rows are one step old)" if world > 1 else ""),
                        "envs_global": n_global, "parallelism": "env-sharded dp%d" % world,
                        **({"domain_randomisation": "mass_scale U(0.8,1.2) per body, friction U(0.5,1.25), seed 1"}

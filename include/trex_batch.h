@@ -16,7 +16,10 @@
  *   - "device" pointers are caller-owned HIP device buffers (e.g. torch tensors' data_ptr()) on the
  *     batch's device. Every batch call validates each distinct pointer once (hipPointerGetAttributes +
  *     allocation range, cached per batch): host memory, another device's memory or a buffer shorter than
- *     the call needs returns TREX_E_INVALID instead of faulting the GPU.
+ *     the call needs returns TREX_E_INVALID instead of faulting the GPU. The cache is keyed by address: a
+ *     buffer that was validated must stay allocated for as long as it is passed to the batch; a caller that
+ *     FREES buffers it has passed (and may get the address back for a shorter or foreign allocation) calls
+ *     trex_batch_forget_buffers() after freeing.
  *   - joints are always exposed in the reference's observation order: revolute joint names
  *     sorted (trex_robot.py:311-314); J = trex_model_num_joints() (25 for trex.urdf).
  */
@@ -105,6 +108,16 @@ int trex_batch_create(const TrexModel *model, int num_envs, int device, TrexBatc
 void trex_batch_destroy(TrexBatch *batch);
 int trex_batch_num_envs(const TrexBatch *batch);
 
+/* Forget the validated caller pointers (see the conventions above): the next call validates them afresh. */
+int trex_batch_forget_buffers(TrexBatch *batch);
+
+/* Which wave runs which env. All waves of a launch of <= 4096 envs are resident at once and a SIMD is done when
+ * its slowest wave is, so the step kernel can rank the envs by the contact count of their previous step and deal
+ * them to the SIMDs heaviest-with-lightest (device-side state only; results are bitwise independent of it).
+ * mode -1 (default): on for batches of 2048 envs or more - below that most SIMDs hold at most two waves and there is
+ * nothing to level -, 0: off (workgroup k runs env k), 1: on for any size. */
+int trex_batch_set_wave_balance(TrexBatch *batch, int mode);
+
 /* reward weights (trex_env.py:42-44): distance, energy, drift. Defaults 1.0, 0.005, 0.002. */
 int trex_batch_set_reward_weights(TrexBatch *batch, float distance, float energy, float drift);
 
@@ -130,8 +143,8 @@ int trex_batch_step(TrexBatch *batch, const float *actions_dev, float *obs_dev, 
  *   rows_dev [N, row_stride] f32 device, row_stride >= 3J + 2:
  *     [0, 3J) observation, [3J] reward, [3J+1] done as 0.0 / 1.0; columns beyond 3J+2 are not touched.
  * done_dev [N] u8, nullable: the done flags once more as bytes (what a consumer masks with - saves it a
- *   conversion pass over the column). trex_batch_reset_rows writes the observation columns only (of every env,
- *   reset or not). */
+ *   conversion pass over the column). trex_batch_reset_rows writes the observation columns of every env (reset or
+ *   not) and, for the envs it resets, reward = 0 and done = 0: the row of a new episode. */
 int trex_batch_step_rows(TrexBatch *batch, const float *actions_dev, float *rows_dev, int row_stride,
                          float *penalties_dev, uint8_t *done_dev, void *stream);
 int trex_batch_reset_rows(TrexBatch *batch, const uint8_t *mask_dev, float *rows_dev, int row_stride, void *stream);

@@ -318,26 +318,23 @@ def test_rank_lists_cover_every_env_at_ragged_sizes(n, model):
     """The env-to-wave assignment is made inside the step kernel from lists the previous launch filed (two list sets,
     flipped by the last wave to end; blocks of 1024 ranks, the last one partial here): over many launches, through
     landing, EVERY env must be stepped exactly once per launch - the trajectories equal those of launches that keep
-    env k in workgroup k (TREX_NO_BALANCE), bitwise."""
+    env k in workgroup k (trex_batch_set_wave_balance(0)), bitwise."""
     lo = torch.tensor(model["q_lower"][model["obs_order"]], dtype=torch.float32, device=DEV)
     hi = torch.tensor(model["q_upper"][model["obs_order"]], dtype=torch.float32, device=DEV)
     g = torch.Generator(device=DEV).manual_seed(5)
     acts = [(lo + (hi - lo) * torch.rand(n, 25, device=DEV, generator=g)).contiguous() for _ in range(70)]
 
     def run(no_balance):
+        v = make_vec(n, max_episode_steps=50)
         if no_balance:
-            os.environ["TREX_NO_BALANCE"] = "1"
-        try:
-            v = make_vec(n, max_episode_steps=50)
-            v.reset_tensor()
-            v.set_episode_steps(torch.arange(n, device=DEV, dtype=torch.int32) % 50)   # resets inside the launches, too
-            for a in acts:
-                o, r, d = v.step_tensor(a)
-            cnt = torch.zeros(n, dtype=torch.int32, device=DEV)
-            v.batch.contact_stats(cnt, None)
-            return o.clone(), r.clone(), v.get_state().clone(), cnt
-        finally:
-            os.environ.pop("TREX_NO_BALANCE", None)
+            v.batch.set_wave_balance(0)
+        v.reset_tensor()
+        v.set_episode_steps(torch.arange(n, device=DEV, dtype=torch.int32) % 50)   # resets inside the launches, too
+        for a in acts:
+            o, r, d = v.step_tensor(a)
+        cnt = torch.zeros(n, dtype=torch.int32, device=DEV)
+        v.batch.contact_stats(cnt, None)
+        return o.clone(), r.clone(), v.get_state().clone(), cnt
 
     o1, r1, s1, c1 = run(False)
     o2, r2, s2, c2 = run(True)
@@ -398,6 +395,52 @@ def test_two_row_blocks_written_in_turn():
             assert two.rows.data_ptr() == blocks[-2][0]
         blocks.append((two.rows.data_ptr(), two.rows, two.rows.clone()))
     assert bool(d2.any()) is False and int(two.episode_steps.max()) <= 7
+
+
+def test_reset_with_the_done_flags_of_the_last_step():
+    """reset_tensor(done): the bool flags step_tensor hands out are a valid reset mask (same bytes as uint8), and the
+    rows of the envs that were reset read reward 0, done 0 afterwards - a consumer that gathers `rows` right after a
+    reset must not see the finished episode's flags."""
+    a = torch.zeros(6, 25, device=DEV)
+    v = make_vec(6, max_episode_steps=4)
+    first = v.reset_tensor().clone()
+    v.set_episode_steps(torch.tensor([3, 0, 3, 0, 0, 0], dtype=torch.int32))
+    o, r, d = v.step_tensor(a)
+    assert d.dtype == torch.bool and d.tolist() == [True, False, True, False, False, False]
+    assert v.done_f.tolist() == [1.0, 0.0, 1.0, 0.0, 0.0, 0.0] and bool((v.rew != 0).all())
+    keep_rew = v.rew.clone()
+    obs = v.reset_tensor(d)                      # bool mask; d IS v.done
+    assert (obs[0] == first[0]).all() and (obs[2] == first[2]).all()
+    assert v.done.tolist() == [False] * 6 and v.done_f.tolist() == [0.0] * 6
+    assert v.rew[0].item() == 0.0 and v.rew[2].item() == 0.0
+    assert (v.rew[[1, 3, 4, 5]] == keep_rew[[1, 3, 4, 5]]).all()       # untouched rows keep their columns
+    with pytest.raises(Exception):
+        v.reset_tensor(torch.zeros(6, dtype=torch.int32, device=DEV))  # neither uint8 nor bool
+
+
+def test_wave_balance_setting_is_a_batch_property():
+    """trex_batch_set_wave_balance: -1 auto (on from 2048 envs), 0 off, 1 on. Results are bitwise independent of it -
+    also when it is forced on below the automatic threshold and when it is switched while the batch is running."""
+    n = 300
+    g = torch.Generator(device=DEV).manual_seed(9)
+    lo = torch.tensor(make_vec(1).model.lower, dtype=torch.float32, device=DEV)
+    hi = torch.tensor(make_vec(1).model.upper, dtype=torch.float32, device=DEV)
+    acts = [(lo + (hi - lo) * torch.rand(n, 25, device=DEV, generator=g)).contiguous() for _ in range(45)]
+    outs = []
+    for mode in (-1, 1, "switch"):
+        v = make_vec(n)
+        if mode == 1:
+            v.batch.set_wave_balance(1)
+        v.reset_tensor()
+        for t, a in enumerate(acts):
+            if mode == "switch":
+                v.batch.set_wave_balance(1 if (t // 7) % 2 else 0)
+            o, r, _ = v.step_tensor(a)
+        outs.append((o.clone(), r.clone(), v.get_state().clone()))
+    for o, r, s in outs[1:]:
+        assert (o == outs[0][0]).all() and (r == outs[0][1]).all() and (s == outs[0][2]).all()
+    with pytest.raises(Exception):
+        v.batch.set_wave_balance(2)
 
 
 def test_full_masked_reset_and_state_round_trip(full):
@@ -514,6 +557,7 @@ def test_config4_size_on_one_gpu(oracle64, oracle32, model):
     # oracle parity on a 64-env sample: the 32 envs with the most contacts + 32 spread over the batch
     idx = torch.cat([torch.argsort(cnt, descending=True)[:32], torch.arange(0, n, n // 32, device=DEV)[:32]]).cpu().numpy()
     st_h, a_h, o_h, r_h, c_h = st.cpu().numpy(), a.cpu().numpy(), o1.cpu().numpy(), r1.cpu().numpy(), cnt.cpu().numpy()
+    fallback, worst_ratio = [], 0.0
     for e in idx:
         s = oracle64.new_state()
         oracle64.set_state(s, st_h[e].astype(np.float64))
@@ -529,13 +573,21 @@ def test_config4_size_on_one_gpu(oracle64, oracle32, model):
             # An ill-conditioned state (a 5 kg toe under kN contact forces, 60 unconverged sweeps): f32 itself is
             # the limit there. The yardstick is the oracle's OWN f32 build against its f64 build on this state -
             # the kernel (another f32 evaluation, different operation order) must stay within 3x that spread.
+            # The stated tolerance stays mandatory for every state whose f32 spread is small, and the number of
+            # states that may take this way out is bounded below.
             s32 = oracle32.new_state()
             oracle32.set_state(s32, st_h[e].astype(np.float64))
             o32, r32, _ = oracle32.step(s32, a_h[e].astype(np.float64))
             spread = np.abs(o32[:50] - o[:50])
             assert spread[25:].max() > 1e-3 * max(1.0, np.abs(o[25:50]).max()), "well-conditioned state out of tolerance"
-            assert (np.abs(o_h[e][:50] - o[:50]) <= 3 * spread + 1e-6).all(), "config-4 env %d beyond 3x the f32 spread" % e
+            err = np.abs(o_h[e][:50] - o[:50])
+            assert (err <= 3 * spread + 1e-6).all(), "config-4 env %d beyond 3x the f32 spread" % e
+            fallback.append(int(e))
+            worst_ratio = max(worst_ratio, float((err / (spread + 1e-6)).max()))
         assert len(oracle64.contacts(s)[0]) == c_h[e]
+    print("config-4 sample: %d of %d states judged by the f32-spread yardstick %s, worst error / spread %.2f"
+          % (len(fallback), len(idx), fallback, worst_ratio))
+    assert len(fallback) <= 3, "too many states outside the stated tolerance: %s" % fallback
 
 
 @pytest.mark.parametrize("n", [1, 3, 63, 4095])

@@ -126,9 +126,9 @@ def _pipe_worker(rank, world, port, ret, in_place=False):
         assert local.shape == (3, 5)
         if in_place:
             blocks[t & 1].copy_(local)                    # "step t" writes block t & 1 ...
-            prev = pipe.push(blocks[t & 1], copy=False, wait=False)   # ... which is gathered where it lies
-            if prev is not None:
-                pipe.last_work().wait()                   # (wait=False: the consumer orders itself behind the gather)
+            # ... which is gathered where it lies. NO consumer-side wait here: push() itself orders the producer
+            # behind the gather that reads the block the next step rewrites (and thereby the returned rows too)
+            prev = pipe.push(blocks[t & 1], copy=False, wait=False)
         else:
             prev = pipe.push(local)
             local.fill_(-1.0)    # the caller may overwrite its rows at once (they were staged)
@@ -152,3 +152,66 @@ def test_pipelined_gather_returns_the_previous_step(tmp_path, in_place):
     for t in range(1, 5):
         want = torch.cat([torch.full((3, 5), float(10 * (t - 1) + r)) for r in range(2)])
         assert torch.equal(got[t], want), t
+
+
+class _FakeWork:
+    def __init__(self, log, t):
+        self.log, self.t = log, t
+
+    def wait(self):
+        self.log.append(("wait", self.t))
+
+
+@pytest.mark.parametrize("wait", [False, True])
+def test_in_place_gather_orders_the_producer_before_it_rewrites_a_block(monkeypatch, wait):
+    """The ordering rule of the in-place pipelined gather, checked with recording fakes for the collective's work
+    handles: step t+2 rewrites the block that gather t reads, so the producer's stream must have been made to wait
+    for gather t BEFORE step t+2 is enqueued - whatever `wait` says (bench.py --gpus N runs wait=False with no
+    consumer). Round 2's push() waited for gather t only at the top of push(t+2), after the write: this test fails
+    on that code."""
+    from trex_gym import sharding
+    log = []
+
+    def fake_all_gather(out, src, group=None, async_op=False):
+        t = sum(1 for e in log if e[0] == "gather")
+        log.append(("gather", t, src.data_ptr()))
+        assert async_op
+        return _FakeWork(log, t)
+
+    monkeypatch.setattr(sharding.dist, "all_gather_into_tensor", fake_all_gather)
+    pipe = sharding.PipelinedGather(3, 5, 2, torch.float32, "cpu")
+    blocks = [torch.zeros(3, 5), torch.zeros(3, 5)]
+    for t in range(6):
+        log.append(("write", t, blocks[t & 1].data_ptr()))     # the step launch that fills block t & 1
+        pipe.push(blocks[t & 1], copy=False, wait=wait)
+    # every gather reads the block that was just written, in place
+    for e in log:
+        if e[0] == "gather":
+            assert e[2] == blocks[e[1] & 1].data_ptr()
+    for t in range(2, 6):
+        i_write = log.index(("write", t, blocks[t & 1].data_ptr()))
+        i_gather = next(i for i, e in enumerate(log) if e[0] == "gather" and e[1] == t - 2)
+        waits = [i for i, e in enumerate(log) if e == ("wait", t - 2)]
+        assert waits and i_gather < min(waits) < i_write, (t, log)
+    # exactly one cross-stream wait per step in the steady state
+    assert sum(1 for e in log if e[0] == "wait") == 5
+
+
+def test_staged_gather_protects_its_staging_block(monkeypatch):
+    """copy=True, wait=False: the staging block of call t is overwritten by call t+2 - behind gather t."""
+    from trex_gym import sharding
+    log = []
+
+    def fake_all_gather(out, src, group=None, async_op=False):
+        t = sum(1 for e in log if e[0] == "gather")
+        log.append(("gather", t, src.data_ptr()))
+        return _FakeWork(log, t)
+
+    monkeypatch.setattr(sharding.dist, "all_gather_into_tensor", fake_all_gather)
+    pipe = sharding.PipelinedGather(3, 5, 2, torch.float32, "cpu")
+    local = torch.zeros(3, 5)
+    for t in range(5):
+        pipe.push(local, copy=True, wait=False)
+    for t in range(2, 5):
+        i_gather_t = next(i for i, e in enumerate(log) if e[0] == "gather" and e[1] == t)
+        assert ("wait", t - 2) in log[:i_gather_t]       # before stage[t & 1] was refilled for gather t

@@ -15,9 +15,9 @@
 
 extern "C" {
 hipError_t trex_launch_step(const TrexDeviceModel *, TrexBatchArrays, int, const float *, float *, float *, uint8_t *,
-                            float *, float, float, float, float *, hipStream_t, float *, int, int);
+                            float *, float, float, float, float *, hipStream_t, float *, int, int, int);
 hipError_t trex_launch_reset(const TrexDeviceModel *, TrexBatchArrays, int, const uint8_t *, float *, float, float,
-                             float, float *, hipStream_t, int);
+                             float, float *, hipStream_t, int, float *, float *, int);
 hipError_t trex_launch_pack_state(const TrexDeviceModel *, TrexBatchArrays, int, float *, int, hipStream_t);
 hipError_t trex_launch_head(const TrexDeviceModel *, TrexBatchArrays, int, float *, hipStream_t);
 hipError_t trex_launch_link_transforms(const TrexDeviceModel *, TrexBatchArrays, int, float *, hipStream_t);
@@ -37,6 +37,8 @@ struct TrexBatch {
   TrexDeviceModel *dmodel = nullptr;
   TrexBatchArrays arr{};
   float wd = 1.0f, we = 0.005f, wk = 0.002f;  // trex_env.py:42-44
+  int balance_mode = -1;                       // trex_batch_set_wave_balance: -1 auto, 0 off, 1 on
+  bool balance() const { return balance_mode < 0 ? n >= 2048 : balance_mode != 0; }
   std::vector<void *> allocs;
   // caller buffers already validated as memory of this device (base address -> bytes known to be good):
   // the hot path pays one hash-free scan of a handful of entries, hipPointerGetAttributes only on a new one
@@ -450,6 +452,19 @@ int trex_batch_set_reward_weights(TrexBatch *b, float distance, float energy, fl
   return TREX_OK;
 }
 
+int trex_batch_set_wave_balance(TrexBatch *b, int mode) {
+  if (check_batch(b)) return TREX_E_INVALID;
+  if (mode < -1 || mode > 1) return fail(TREX_E_INVALID, "trex_batch_set_wave_balance: mode must be -1 (auto), 0 (off) or 1 (on)");
+  b->balance_mode = mode;
+  return TREX_OK;
+}
+
+int trex_batch_forget_buffers(TrexBatch *b) {
+  if (check_batch(b)) return TREX_E_INVALID;
+  b->seen.clear();
+  return TREX_OK;
+}
+
 int trex_batch_reset(TrexBatch *b, const uint8_t *mask_dev, float *obs_out_dev, void *stream) {
   if (check_batch(b)) return TREX_E_INVALID;
   DeviceGuard guard(b->device);
@@ -457,7 +472,7 @@ int trex_batch_reset(TrexBatch *b, const uint8_t *mask_dev, float *obs_out_dev, 
   BUF_TRY(mask_dev, n, "trex_batch_reset: mask");
   BUF_TRY(obs_out_dev, n * 3 * b->nj * sizeof(float), "trex_batch_reset: obs_out");
   HIP_TRY(trex_launch_reset(b->dmodel, b->arr, b->n, mask_dev, obs_out_dev, b->wd, b->we, b->wk, nullptr,
-                            (hipStream_t)stream, 3 * b->nj));
+                            (hipStream_t)stream, 3 * b->nj, nullptr, nullptr, 1));
   return TREX_OK;
 }
 
@@ -470,7 +485,7 @@ int trex_batch_reset_rows(TrexBatch *b, const uint8_t *mask_dev, float *rows_dev
   BUF_TRY(mask_dev, n, "trex_batch_reset_rows: mask");
   BUF_TRY(rows_dev, ((n - 1) * row_stride + 3 * b->nj + 2) * sizeof(float), "trex_batch_reset_rows: rows");
   HIP_TRY(trex_launch_reset(b->dmodel, b->arr, b->n, mask_dev, rows_dev, b->wd, b->we, b->wk, nullptr,
-                            (hipStream_t)stream, row_stride));
+                            (hipStream_t)stream, row_stride, rows_dev + 3 * b->nj, rows_dev + 3 * b->nj + 1, row_stride));
   return TREX_OK;
 }
 
@@ -486,7 +501,7 @@ int trex_batch_step(TrexBatch *b, const float *actions_dev, float *obs_dev, floa
   BUF_TRY(done_dev, n, "trex_batch_step: done");
   BUF_TRY(penalties_dev, n * 3 * sizeof(float), "trex_batch_step: penalties");
   HIP_TRY(trex_launch_step(b->dmodel, b->arr, b->n, actions_dev, obs_dev, reward_dev, done_dev, penalties_dev, b->wd,
-                           b->we, b->wk, nullptr, (hipStream_t)stream, nullptr, 3 * b->nj, 1));
+                           b->we, b->wk, nullptr, (hipStream_t)stream, nullptr, 3 * b->nj, 1, b->balance()));
   return TREX_OK;
 }
 
@@ -503,7 +518,7 @@ int trex_batch_step_rows(TrexBatch *b, const float *actions_dev, float *rows_dev
   BUF_TRY(done_dev, n, "trex_batch_step_rows: done");
   float *rew = rows_dev + 3 * b->nj;
   HIP_TRY(trex_launch_step(b->dmodel, b->arr, b->n, actions_dev, rows_dev, rew, done_dev, penalties_dev, b->wd, b->we,
-                           b->wk, nullptr, (hipStream_t)stream, rew + 1, row_stride, row_stride));
+                           b->wk, nullptr, (hipStream_t)stream, rew + 1, row_stride, row_stride, b->balance()));
   return TREX_OK;
 }
 
@@ -515,7 +530,7 @@ int trex_batch_debug_step(TrexBatch *b, const float *actions_dev, float *obs_dev
   BUF_TRY(obs_dev, (size_t)b->n * 3 * b->nj * sizeof(float), "trex_batch_debug_step: obs");
   BUF_TRY(debug_dev, 4096 * sizeof(float), "trex_batch_debug_step: debug");   // (diagnostic builds: 4096 + 16 N)
   HIP_TRY(trex_launch_step(b->dmodel, b->arr, b->n, actions_dev, obs_dev, nullptr, nullptr, nullptr, b->wd, b->we, b->wk,
-                           debug_dev, (hipStream_t)stream, nullptr, 3 * b->nj, 1));
+                           debug_dev, (hipStream_t)stream, nullptr, 3 * b->nj, 1, b->balance()));
   return TREX_OK;
 }
 
@@ -637,7 +652,7 @@ int trex_batch_time_steps(TrexBatch *b, const float *actions_dev, float *obs_dev
   HIP_TRY(hipEventRecord(e0, s));
   for (int i = 0; i < steps; i++)
     HIP_TRY(trex_launch_step(b->dmodel, b->arr, b->n, actions_dev, obs_dev, reward_dev, done_dev, nullptr, b->wd, b->we,
-                             b->wk, nullptr, s, nullptr, 3 * b->nj, 1));
+                             b->wk, nullptr, s, nullptr, 3 * b->nj, 1, b->balance()));
   HIP_TRY(hipEventRecord(e1, s));
   HIP_TRY(hipEventSynchronize(e1));
   float ms = 0.f;

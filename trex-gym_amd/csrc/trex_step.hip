@@ -38,8 +38,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <stdlib.h>
-
 #include <type_traits>
 
 #include "device_model.h"
@@ -376,14 +374,22 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
     int r = q == 0 ? k : (q << 10) + (m - 1 - (k & 1023));
     const int lane_ = (int)threadIdx.x;
     const int mine = lane_ < TREX_BAL_BINS ? cnt[lane_] : 0;   // the 16 counts in one load, lane c holds count c
-    int b = TREX_BAL_BINS - 1;
+    int b = TREX_BAL_BINS - 1, total = 0;
+#pragma unroll
+    for (int c = 0; c < TREX_BAL_BINS; c++) total += rl(mine, c);
     for (; b > 0; b--) {
       const int c = rl(mine, b);
       if (r < c) break;
       r -= c;
     }
-    env = B[TREX_BAL_LISTS + (size_t)(bal_phase * TREX_BAL_BINS + b) * args.n_envs + r];
-    env = min(max(env, 0), args.n_envs - 1);
+    // The lists are sound exactly when they hold every env once: the counts sum to n_envs (every wave sees the same
+    // counts and takes the same decision). If they do not - a launch that did not complete left them half filed -
+    // this launch keeps env k in workgroup k instead of stepping one env twice and another not at all; its waves
+    // still file their envs below, so the next launch finds sound lists again.
+    if (total == args.n_envs) {
+      env = B[TREX_BAL_LISTS + (size_t)(bal_phase * TREX_BAL_BINS + b) * args.n_envs + r];
+      if (env < 0 || env >= args.n_envs) env = blockIdx.x;   // (unreachable with sound lists; never an out-of-range row)
+    }
   }
   env = uni(env);
 
@@ -1900,11 +1906,13 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
     o[obs_slot] = q; o[nj + obs_slot] = qd; o[2 * nj + obs_slot] = mtau;
   }
   if (lt == 0) {
-    if (args.reward) args.reward[(size_t)env * args.scal_stride] = env_bad ? 0.f : -lift - drift - energy;
+    // (RESET launches carry the reward / done pointers only for trex_batch_reset_rows: the env that was reset
+    // starts its episode with reward 0, done 0 in the caller's row block)
+    if (args.reward) args.reward[(size_t)env * args.scal_stride] = (RESET || env_bad) ? 0.f : -lift - drift - energy;
     // should_terminate() is constant False (trex_env.py:183-184): done only flags the harness's episode limit and
     // a contained non-finite env
-    if (args.done) args.done[env] = (env_bad || time_up) ? 1 : 0;
-    if (args.done_f) args.done_f[(size_t)env * args.scal_stride] = (env_bad || time_up) ? 1.f : 0.f;
+    if (args.done) args.done[env] = (!RESET && (env_bad || time_up)) ? 1 : 0;
+    if (args.done_f) args.done_f[(size_t)env * args.scal_stride] = (!RESET && (env_bad || time_up)) ? 1.f : 0.f;
     if (args.penalties) {
       args.penalties[env * 3 + 0] = env_bad ? 0.f : lift; args.penalties[env * 3 + 1] = env_bad ? 0.f : drift;
       args.penalties[env * 3 + 2] = env_bad ? 0.f : energy;
@@ -2074,10 +2082,11 @@ extern "C" {
 
 hipError_t trex_launch_step(const TrexDeviceModel *model, TrexBatchArrays arr, int n, const float *actions,
                             float *obs, float *reward, uint8_t *done, float *penalties, float wd, float we,
-                            float wk, float *debug, hipStream_t stream, float *done_f, int obs_stride, int scal_stride) {
-  // diagnostics launches keep env k in workgroup k (the stamped build is balanced like the product: it reports
-  // the env of every wave)
-  int32_t *perm = ((debug && !TREX_STAMPS) || n < 2048 || getenv("TREX_NO_BALANCE")) ? nullptr : arr.balance;
+                            float wk, float *debug, hipStream_t stream, float *done_f, int obs_stride, int scal_stride,
+                            int balance) {
+  // balance: the env-to-wave assignment by contact rank (trex_batch_set_wave_balance decides; capi.cpp). Diagnostics
+  // launches keep env k in workgroup k (the stamped build is balanced like the product: it reports the env of every wave)
+  int32_t *perm = ((debug && !TREX_STAMPS) || !balance) ? nullptr : arr.balance;
   KernelArgs a{model, arr, n, actions, obs, reward, done, done_f, obs_stride, scal_stride, penalties, nullptr, perm, wd, we, wk, debug};
 #if TREX_STAMPS   // diagnostic build: the PRODUCT instantiation, stamped (the dump of <false, true> would change its code)
   hipLaunchKernelGGL((trex_step_kernel<false, false>), dim3(n), dim3(64), 0, stream, a);
@@ -2089,8 +2098,9 @@ hipError_t trex_launch_step(const TrexDeviceModel *model, TrexBatchArrays arr, i
 }
 
 hipError_t trex_launch_reset(const TrexDeviceModel *model, TrexBatchArrays arr, int n, const uint8_t *mask,
-                             float *obs, float wd, float we, float wk, float *debug, hipStream_t stream, int obs_stride) {
-  KernelArgs a{model, arr, n, nullptr, obs, nullptr, nullptr, nullptr, obs_stride, 1, nullptr, mask, nullptr, wd, we, wk, debug};
+                             float *obs, float wd, float we, float wk, float *debug, hipStream_t stream, int obs_stride,
+                             float *reward, float *done_f, int scal_stride) {
+  KernelArgs a{model, arr, n, nullptr, obs, reward, nullptr, done_f, obs_stride, scal_stride, nullptr, mask, nullptr, wd, we, wk, debug};
   hipLaunchKernelGGL((trex_step_kernel<true, false>), dim3(n), dim3(64), 0, stream, a);
   return hipGetLastError();
 }

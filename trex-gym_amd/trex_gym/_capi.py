@@ -38,6 +38,7 @@ SYMBOLS = [
     "trex_model_use_primitive_collision", "trex_model_fit_hull_primitives",
     "trex_build_id", "trex_batch_step_rows", "trex_batch_reset_rows",
     "trex_batch_set_episode_limit", "trex_batch_get_episode_steps",
+    "trex_batch_set_wave_balance", "trex_batch_forget_buffers",
 ]
 
 _vp = C.c_void_p
@@ -69,6 +70,8 @@ lib.trex_batch_step_rows.argtypes = [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp]
 lib.trex_batch_reset_rows.argtypes = [_vp, _vp, _vp, C.c_int, _vp]
 lib.trex_batch_set_episode_limit.argtypes = [_vp, C.c_int, _vp, _vp]
 lib.trex_batch_get_episode_steps.argtypes = [_vp, _vp, _vp]
+lib.trex_batch_set_wave_balance.argtypes = [_vp, C.c_int]
+lib.trex_batch_forget_buffers.argtypes = [_vp]
 lib.trex_batch_debug_step.argtypes = [_vp, _vp, _vp, _vp, _vp]
 lib.trex_batch_get_state.argtypes = [_vp, _vp, _vp]
 lib.trex_batch_set_state.argtypes = [_vp, _vp, _vp]
@@ -245,9 +248,23 @@ class Batch:
         import torch
         return _ptr(t, self.device, getattr(torch, dtype), numel, what)
 
+    def _mask(self, mask):
+        """reset mask [n]: uint8 or bool (the same byte layout; step_rows hands `done` out as bool)."""
+        import torch
+        if mask is not None and mask.dtype not in (torch.uint8, torch.bool):
+            raise TrexError(E_INVALID, "mask: expected dtype uint8 or bool, got %s" % mask.dtype)
+        return _ptr(mask, self.device, None, self.num_envs, "mask")
+
+    def set_wave_balance(self, mode):
+        """-1 auto (on from 2048 envs), 0 off (workgroup k runs env k), 1 on: include/trex_batch.h."""
+        check(lib.trex_batch_set_wave_balance(self.h, int(mode)))
+
+    def forget_buffers(self):
+        check(lib.trex_batch_forget_buffers(self.h))
+
     def reset(self, obs_out=None, mask=None, stream=None):
         n, J = self.num_envs, self.J
-        check(lib.trex_batch_reset(self.h, self._p(mask, "uint8", n, "mask"), self._p(obs_out, "float32", n * 3 * J, "obs_out"),
+        check(lib.trex_batch_reset(self.h, self._mask(mask), self._p(obs_out, "float32", n * 3 * J, "obs_out"),
                                    self._stream(stream)))
 
     def step(self, actions, obs, reward, done, penalties=None, stream=None):
@@ -270,7 +287,7 @@ class Batch:
 
     def reset_rows(self, rows, mask=None, stream=None):
         n, J = self.num_envs, self.J
-        check(lib.trex_batch_reset_rows(self.h, self._p(mask, "uint8", n, "mask"),
+        check(lib.trex_batch_reset_rows(self.h, self._mask(mask),
                                         self._p(rows, "float32", n * (3 * J + 2), "rows"), int(rows.shape[1]),
                                         self._stream(stream)))
 

@@ -84,12 +84,19 @@ def all_gather_rows(local, global_rows, world_size, group=None, out=None):
 
 
 class PipelinedGather:
-    """All-gather of the per-rank observation rows that overlaps the NEXT env step: the rows are copied
-    to one of two staging blocks on the compute stream (stream-ordered after the step that produced them),
-    the collective is launched asynchronously on the communicator's stream, and the call returns the
-    block gathered ONE call earlier - complete by then, or made so by waiting on its work handle. A
+    """All-gather of the per-rank observation rows that overlaps the NEXT env step: the collective is launched
+    asynchronously on the communicator's stream and the call returns the block gathered ONE call earlier. A
     centralised consumer therefore sees observations one step late, and no step waits for xGMI.
-    Equal shards only (the bench / trainer case); ragged shards go through all_gather_rows."""
+    Equal shards only (the bench / trainer case); ragged shards go through all_gather_rows.
+
+    Two forms. copy=True: the rows are first copied to one of two staging blocks on the caller's stream; the caller
+    may overwrite its rows at once. copy=False: the rows are gathered IN PLACE from a producer that writes two row
+    blocks in turn (TrexVecEnv(row_buffers=2)): the gather G(t) of step t's block is still reading it while step
+    t+1 fills the other one, and step t+2 rewrites it. ORDERING RULE of the in-place form: push(t+1) - which runs
+    between the launches of step t+1 and step t+2 - makes the caller's stream wait for G(t), always, whatever
+    `wait` says. That is the one cross-stream wait per step, and it is the one that orders step t+2 behind the last
+    reader of the block it rewrites. (Round 2 waited for G(t) at the top of push(t+2), AFTER step t+2 had been
+    enqueued: a write-after-read race whenever a gather outlives the following step.)"""
 
     def __init__(self, rows_local, cols, world_size, dtype, device, group=None):
         self.world, self.group = int(world_size), group
@@ -100,25 +107,27 @@ class PipelinedGather:
 
     def push(self, local, copy=True, wait=True):
         """Launch the gather of `local`; returns the previous call's gathered rows (None on the first).
-        copy=False: `local` is gathered in place - the caller leaves it untouched until the call after the
-        next has returned (a producer that alternates between two row blocks does: TrexVecEnv(row_buffers=2)),
-        and no staging copy sits between two steps on the compute stream.
-        wait=False: the returned rows are NOT yet ordered before the caller's stream (a consumer on another stream
-        orders itself behind `last_work()`); the producer's stream then carries one cross-stream wait per step - the
-        one that protects the block about to be rewritten - instead of two."""
-        k = self.k
-        if self.work[k] is not None:     # the collective that last read stage[k] / wrote out[k]
-            self.work[k].wait()
+        copy=False: `local` is gathered in place; the caller must not write it before the NEXT push() has returned
+        (that push orders the caller's stream behind this gather) - a producer alternating between two row blocks
+        and pushing after every step satisfies that by construction.
+        wait=False (staged form only): the returned rows are NOT ordered before the caller's stream; a consumer on
+        another stream orders itself behind `last_work()`. The in-place form always orders them (see the class note)."""
+        k, prev = self.k, 1 - self.k
         src = local
         if copy:
+            # stage[k] was last read by the gather of two calls ago (complete unless wait=False skipped its wait)
+            if self.work[k] is not None:
+                self.work[k].wait()
             self.stage[k].copy_(local)
             src = self.stage[k]
+        # (out[k], last written by the gather of two calls ago, is rewritten behind it: the communicator's stream is
+        # in order; a wait=False consumer still reading out[k] holds that gather's work handle and must be done with it)
         self.work[k] = dist.all_gather_into_tensor(self.out[k], src, group=self.group, async_op=True)
-        prev = 1 - k
         self.k = prev
         if self.work[prev] is None:
             return None
-        if wait:
+        if wait or not copy:
+            # in place: the block the producer's NEXT step rewrites is the one work[prev] is reading
             self.work[prev].wait()
         return self.out[prev]
 

@@ -81,8 +81,13 @@ class TrexVecEnv:
 
     # ---- tensor-native API (stays on device, stream-ordered, no host sync)
     def reset_tensor(self, mask=None):
-        """Reset all envs (mask=None) or those with mask != 0 (uint8 [n]). Returns obs [n, 3J]."""
+        """Reset all envs (mask=None) or those with mask != 0 (uint8 or bool [n], e.g. the `done` of the last step).
+        Returns obs [n, 3J]; the reward / done columns and `done` of the envs that were reset read 0 afterwards."""
         self.batch.reset_rows(self.rows, mask)
+        if mask is None:
+            self.done.zero_()
+        else:
+            self.done.logical_and_(mask == 0)     # (also correct for mask is self.done)
         return self.obs
 
     @property
