@@ -127,6 +127,9 @@ def _self_launch(n, argv):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TREX_BENCH_SELF_LAUNCHED="1")
+        # like torch.distributed.run: one OpenMP thread per rank unless the caller says otherwise (N ranks x all cores
+        # oversubscribe the host; the gloo rehearsal of the N = 2 path ran 300x slower without this)
+        env.setdefault("OMP_NUM_THREADS", "1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=out0 if r == 0 else sys.stderr))
     rc = 0
@@ -149,7 +152,10 @@ def _self_launch(n, argv):
             if pr.poll() is None:
                 pr.kill()
     out0.seek(0)
-    sys.stdout.write(out0.read().decode())
+    # stdout carries ONE JSON line: anything else rank 0 (or a library under it: gloo prints its connection
+    # notes there) wrote to stdout goes to stderr
+    for line in out0.read().decode().splitlines(True):
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line)
     sys.stdout.flush()
     sys.exit(rc)
 

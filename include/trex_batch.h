@@ -14,8 +14,8 @@
  *     and all of its calls are asynchronous and ordered on the hipStream_t given
  *     (passed as void* so the header needs no HIP include; NULL = the default stream).
  *   - "device" pointers are caller-owned HIP device buffers (e.g. torch tensors' data_ptr()) on the
- *     batch's device. Every batch call validates each distinct pointer once (hipPointerGetAttributes +
- *     allocation range, cached per batch): host memory, another device's memory or a buffer shorter than
+ *     batch's device. Every batch call validates each distinct ALLOCATION once (hipPointerGetAttributes +
+ *     its address range, cached per batch; pointers into a validated allocation are range-checked against it): host memory, another device's memory or a buffer shorter than
  *     the call needs returns TREX_E_INVALID instead of faulting the GPU. The cache is keyed by address: a
  *     buffer that was validated must stay allocated for as long as it is passed to the batch; a caller that
  *     FREES buffers it has passed (and may get the address back for a shorter or foreign allocation) calls
@@ -178,6 +178,17 @@ int trex_batch_head_position(TrexBatch *batch, float *out_dev, void *stream);
 int trex_model_num_links(const TrexModel *model);
 int trex_model_link_info(const TrexModel *model, int link, const char **name, int *body);
 int trex_batch_link_transforms(TrexBatch *batch, float *out_dev, void *stream);
+
+/* The table a renderer needs to place the meshes (trex_env.py:156-181 draws them through pybullet; the reference's
+ * parser holds them as UrdfLink.visual_shapes, tools/urdf_parsing.py:93-120,299-307): every <visual> mesh of the URDF
+ * in document order (252 for trex.urdf) - mesh file name as written in the URDF, index of its link
+ * (trex_model_link_info), and its <origin> in the link frame as position + quaternion xyzw. Any out pointer may be
+ * NULL. trex_batch_visual_transforms: world pose of every mesh, [N, V, 7] f32 device = link pose x <origin> -
+ * no URDF re-parsing, no composition left to the caller. The mesh FILES are the caller's (not loaded here). */
+int trex_model_num_visuals(const TrexModel *model);
+int trex_model_visual_info(const TrexModel *model, int visual, const char **mesh_file, int *link, double xyz[3],
+                           double quat_xyzw[4]);
+int trex_batch_visual_transforms(TrexBatch *batch, float *out_dev, void *stream);
 
 /* domain randomisation (BASELINE config 5; no reference counterpart): per-env mass scale of each
  * moving body [N, num_bodies] and per-env friction coefficient [N]; either may be NULL. */

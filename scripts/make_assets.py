@@ -7,8 +7,10 @@ Run in the authoring container only (needs /root/reference/assets):
 
 Outputs (derived DATA, no reference source code):
 
-  trex-gym_amd/assets/trex_collide.urdf   joints + inertials of assets/trex.urdf, <visual> elements
-                                          dropped, <collision> elements ADDED (the v1 URDF has none,
+  trex-gym_amd/assets/trex_collide.urdf   joints + inertials + <visual> elements of assets/trex.urdf (the 252
+                                          visual origins and mesh file NAMES are what the rollout export places
+                                          meshes with; the 32 MB of .obj files themselves are not shipped),
+                                          <collision> elements ADDED (the v1 URDF has none,
                                           SURVEY F3): each of the 28 convex hulls in
                                           assets/collisions/*.dae is attached to the link that shows
                                           the same-named visual mesh, at that visual's <origin>
@@ -124,13 +126,15 @@ def main():
     out = ET.Element("robot", {"name": robot.get("name")})
     out.append(ET.Comment(
         " generated by scripts/make_assets.py from assets/trex.urdf + assets/collisions/*.dae of "
-        "bingjeff/trex-gym v1: visuals dropped, collision hulls attached (see DESIGN.md) "))
+        "bingjeff/trex-gym v1: visual elements kept (mesh files not shipped), collision hulls attached (see DESIGN.md) "))
     for j in robot.findall("joint"):
         out.append(j)
     n_col = 0
     for link in robot.findall("link"):
         nl = ET.SubElement(out, "link", {"name": link.get("name")})
         nl.append(link.find("inertial"))
+        for v in link.findall("visual"):      # origin + mesh file name, verbatim (rollout export)
+            nl.append(v)
         for obj_name, origin in collisions.get(link.get("name"), []):
             c = ET.SubElement(nl, "collision")
             ET.SubElement(c, "origin", origin)

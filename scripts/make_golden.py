@@ -17,6 +17,10 @@ fixture. What is recorded, all computed by the reference's code:
   fk       pose of every link frame relative to the root link frame at the start pose
            (hips -0.6, knees 0.4, ankles -1.2; trex_env.py:81-87 after the F2 rename),
            composed with geometry.Transform.__mul__ (geometry.py:17-21)
+  visuals  every <visual> mesh as the reference parser reads it (UrdfLink.visual_shapes,
+           urdf_parsing.py:93-120,299-307): link, mesh file name, origin xyz + quaternion; and its pose at the
+           start pose relative to the root link frame, fk[link] * shape.origin (what a renderer places the mesh
+           with, trex_env.py:156-181)
 """
 import json
 import os
@@ -84,10 +88,15 @@ def main():
     out["com_start_pose"] = {
         l.name: (poses[l.name].apply(l.inertia.origin.translation)).tolist()
         for l in urdf.links.values()}
+    out["visuals"] = []
+    for l in urdf.links.values():
+        for shape in l.visual_shapes:
+            out["visuals"].append({"link": l.name, "file": shape.filename, "origin": tf(shape.origin),
+                                   "pose_start": tf(poses[l.name] * shape.origin)})
     with open(OUT, "w") as f:
         json.dump(out, f, indent=0, separators=(",", ":"))
     print("joints", len(out["joints"]), "links", len(out["links"]),
-          "chains", len(out["tree"]["joint_chains"]), "branch", len(out["tree"]["branch_link_names"]),
+          "visuals", len(out["visuals"]), "chains", len(out["tree"]["joint_chains"]), "branch", len(out["tree"]["branch_link_names"]),
           "bytes", os.path.getsize(OUT))
 
 

@@ -151,3 +151,22 @@ def test_primitive_fitting_known_answers_and_oracle_agreement(capi, model):
             assert max(dist(p) for p in pts) < 0.12
     with pytest.raises(capi.TrexError):
         m.use_primitive_collision(-1.0)
+
+
+def test_visual_mesh_table_matches_the_reference_parser(capi):
+    """trex_model_visual_info: the 252 <visual> meshes as the reference's parser reads them (UrdfLink.visual_shapes,
+    tools/urdf_parsing.py:93-120,299-307; fixture written by scripts/make_golden.py importing that parser): file name,
+    link, <origin> as position + quaternion. Host-only: no GPU."""
+    import json
+    from oracle import trex_model as tm
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "urdf_reference.json")))["visuals"]
+    m = capi.Model()
+    links = [n for n, _ in m.links()]
+    table = m.visuals()
+    assert len(table) == len(gold) == 252
+    for (file, link, xyz, quat), g in zip(table, gold):
+        assert file == g["file"] and links[link] == g["link"]
+        np.testing.assert_allclose(xyz, g["origin"]["xyz"], atol=1e-12)
+        np.testing.assert_allclose(tm.quat_to_matrix(quat), tm.quat_to_matrix(g["origin"]["quat_xyzw"]), atol=1e-12)
+    name, link = capi.C.c_char_p(), capi.C.c_int()
+    assert capi.lib.trex_model_visual_info(m.h, 252, capi.C.byref(name), capi.C.byref(link), None, None) == capi.E_INVALID

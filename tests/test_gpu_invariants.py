@@ -148,6 +148,19 @@ def test_link_transforms_match_reference_fk_and_oracle(model, oracle64):
             np.testing.assert_allclose(out[e, k, :3], p, atol=2e-5)
             np.testing.assert_allclose(tm.quat_to_matrix(out[e, k, 3:]), R, atol=2e-5)
             assert out[e, k, 6] >= 0 and abs(np.linalg.norm(out[e, k, 3:]) - 1) < 1e-5
+    # (c) the <visual> meshes (trex_batch_visual_transforms): env 0 == the fixture computed by the reference's parser
+    # and Transform algebra (fk[link] * shape.origin, scripts/make_golden.py), every env == link pose x <origin>
+    vis = v.visual_transforms().cpu().numpy()
+    table = v.model.visuals()
+    assert vis.shape == (n, 252, 7) and len(gold["visuals"]) == 252
+    for k, (g, (file, link, xyz, quat)) in enumerate(zip(gold["visuals"], table)):
+        assert file == g["file"] and names[link] == g["link"]
+        np.testing.assert_allclose(vis[0, k, :3], g["pose_start"]["xyz"], atol=5e-6, err_msg=file)
+        np.testing.assert_allclose(tm.quat_to_matrix(vis[0, k, 3:]), tm.quat_to_matrix(g["pose_start"]["quat_xyzw"]), atol=5e-6, err_msg=file)
+        for e in range(1, n):
+            Rl = tm.quat_to_matrix(out[e, link, 3:])
+            np.testing.assert_allclose(vis[e, k, :3], out[e, link, :3] + Rl @ xyz, atol=2e-5)
+            np.testing.assert_allclose(tm.quat_to_matrix(vis[e, k, 3:]), Rl @ tm.quat_to_matrix(quat), atol=2e-5)
 
 
 def test_step_is_graph_capturable_and_stream_ordered():

@@ -7,8 +7,11 @@ Stated tolerances (f32 kernel vs f64 oracle; PGS amplifies rounding in contact):
   motor torque <= 5e-3 * max|tau| over the unsaturated joints (+1 N m), saturated joints saturated alike,
   reward <= 2e-3 relative (+1e-3, + a tenth of what the qd / tau tolerances allow in the energy term)
   contact-free trajectories (8..25 steps): |dq| <= 1e-4, |dqd| <= 5e-4 * max(1, |qd|_inf)
-Measured over 252 states, 152 of them in contact (scripts/parity_stats.py): max |dq| 3.7e-5,
-|dqd| 7.7e-4, torque 9.0e-4, reward 3.8e-4 (medians 1e-7 .. 3e-6); airborne states 3e-7 .. 1e-5.
+Measured over 252 states, 152 of them in contact (scripts/parity_stats.py on the round-3 kernel,
+profiles/r03_parity_stats.txt): max |dq| 3.4e-5, |dqd| 1.43e-3, torque 1.61e-3, reward 5.5e-4 (medians 1e-7 .. 2e-6);
+airborne states 2e-7 .. 7e-6. Head-room against the 5e-3 rate / torque tolerances: 3.5x. (Round 1's kernel had
+7.7e-4 / 9.0e-4; the round-2 rewrite of the solver - residual form, impulse-shifted bounds - doubled the worst case;
+exact-arithmetic ablation builds show the v_rsq / v_rcp / series shortcuts are not the cause.)
 """
 import os
 

@@ -20,7 +20,7 @@ hipError_t trex_launch_reset(const TrexDeviceModel *, TrexBatchArrays, int, cons
                              float, float *, hipStream_t, int, float *, float *, int);
 hipError_t trex_launch_pack_state(const TrexDeviceModel *, TrexBatchArrays, int, float *, int, hipStream_t);
 hipError_t trex_launch_head(const TrexDeviceModel *, TrexBatchArrays, int, float *, hipStream_t);
-hipError_t trex_launch_link_transforms(const TrexDeviceModel *, TrexBatchArrays, int, float *, hipStream_t);
+hipError_t trex_launch_link_transforms(const TrexDeviceModel *, TrexBatchArrays, int, float *, hipStream_t, int);
 hipError_t trex_launch_fill(float *, float, int, hipStream_t);
 hipError_t trex_launch_fill_u8(uint8_t *, uint8_t, int, hipStream_t);
 hipError_t trex_launch_copy_mass_scale(const float *, float *, int, int, hipStream_t);
@@ -40,7 +40,7 @@ struct TrexBatch {
   int balance_mode = -1;                       // trex_batch_set_wave_balance: -1 auto, 0 off, 1 on
   bool balance() const { return balance_mode < 0 ? n >= 2048 : balance_mode != 0; }
   std::vector<void *> allocs;
-  // caller buffers already validated as memory of this device (base address -> bytes known to be good):
+  // caller allocations already validated as memory of this device (base address, bytes known to be good):
   // the hot path pays one hash-free scan of a handful of entries, hipPointerGetAttributes only on a new one
   struct Seen { const void *p; size_t bytes; };
   std::vector<Seen> seen;
@@ -188,8 +188,13 @@ int check_batch(const TrexBatch *b) { return b ? TREX_OK : fail(TREX_E_INVALID, 
 // header says nullable (the caller checks non-nullable arguments first).
 int check_device_buffer(TrexBatch *b, const void *p, size_t bytes, const char *what) {
   if (!p) return TREX_OK;
-  for (const auto &s : b->seen)
-    if (s.p == p && s.bytes >= bytes) return TREX_OK;
+  // validated ALLOCATIONS of this device: any pointer into one of them with enough room behind it passes without a
+  // runtime query (a caller that walks through one large tensor - a [T, N, J] action pool - presents a new pointer
+  // every step; hipPointerGetAttributes + hipMemGetAddressRange cost about 20 us)
+  for (const auto &s : b->seen) {
+    const char *lo = (const char *)s.p, *q = (const char *)p;
+    if (q >= lo && q + bytes <= lo + s.bytes) return TREX_OK;
+  }
   hipPointerAttribute_t at;
   std::memset(&at, 0, sizeof at);
   hipError_t e = hipPointerGetAttributes(&at, p);
@@ -204,16 +209,19 @@ int check_device_buffer(TrexBatch *b, const void *p, size_t bytes, const char *w
                                     ", the batch on device " + std::to_string(b->device));
   void *base = nullptr;
   size_t size = 0;
+  const void *lo = p;
+  size_t known = bytes;
   if (hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)p) == hipSuccess && base) {
     const size_t left = size - (size_t)((const char *)p - (const char *)base);
     if (left < bytes)
       return fail(TREX_E_INVALID, std::string(what) + ": buffer too small (" + std::to_string(left) + " bytes, need " +
                                       std::to_string(bytes) + ")");
+    lo = base; known = size;   // the whole allocation is good
   } else {
     (void)hipGetLastError();
   }
   if (b->seen.size() >= 64) b->seen.erase(b->seen.begin());
-  b->seen.push_back({p, bytes});
+  b->seen.push_back({lo, known});
   return TREX_OK;
 }
 #define BUF_TRY(p, bytes, what)                                                  \
@@ -409,7 +417,28 @@ int trex_batch_create(const TrexModel *model, int num_envs, int device, TrexBatc
   float *link_tf_dev = nullptr;
   A(nl * sizeof(int), (void **)&link_body_dev);
   A(nl * 12 * sizeof(float), (void **)&link_tf_dev);
+  const size_t nvis = model->host.visual_file.size();
+  int *vis_body_dev = nullptr;
+  float *vis_tf_dev = nullptr;
+  A((nvis ? nvis : 1) * sizeof(int), (void **)&vis_body_dev);
+  A((nvis ? nvis : 1) * 12 * sizeof(float), (void **)&vis_tf_dev);
   if (r != hipSuccess) { cleanup(); return hip_fail(r, "hipMalloc"); }
+  {
+    std::vector<int> vb(nvis);
+    std::vector<float> vtf(nvis * 12);
+    for (size_t v = 0; v < nvis; v++) {
+      vb[v] = model->host.link_body[model->host.visual_link[v]];
+      const trex::Tf &t = model->host.visual_body_tf[v];
+      for (int k = 0; k < 9; k++) vtf[12 * v + k] = (float)t.R.m[k];
+      vtf[12 * v + 9] = (float)t.t.x; vtf[12 * v + 10] = (float)t.t.y; vtf[12 * v + 11] = (float)t.t.z;
+    }
+    b->arr.num_visuals = (int)nvis; b->arr.visual_body = vis_body_dev; b->arr.visual_tf = vis_tf_dev;
+    if (nvis) {
+      r = hipMemcpy(vis_body_dev, vb.data(), nvis * sizeof(int), hipMemcpyHostToDevice);
+      if (r == hipSuccess) r = hipMemcpy(vis_tf_dev, vtf.data(), vtf.size() * sizeof(float), hipMemcpyHostToDevice);
+      if (r != hipSuccess) { cleanup(); return hip_fail(r, "hipMemcpy (visual table)"); }
+    }
+  }
   std::vector<float4> hull(nv ? nv : 1);
   for (size_t i = 0; i < nv; i++) hull[i] = make_float4((float)model->host.hull_xyz[i].x, (float)model->host.hull_xyz[i].y, (float)model->host.hull_xyz[i].z, (float)model->host.hull_radius[i]);
   std::vector<float> ltf(nl * 12);
@@ -601,7 +630,28 @@ int trex_batch_link_transforms(TrexBatch *b, float *out_dev, void *stream) {
   if (!out_dev) return fail(TREX_E_INVALID, "out is null");
   DeviceGuard guard(b->device);
   BUF_TRY(out_dev, (size_t)b->n * b->arr.num_links * 7 * sizeof(float), "trex_batch_link_transforms: out");
-  HIP_TRY(trex_launch_link_transforms(b->dmodel, b->arr, b->n, out_dev, (hipStream_t)stream));
+  HIP_TRY(trex_launch_link_transforms(b->dmodel, b->arr, b->n, out_dev, (hipStream_t)stream, 0));
+  return TREX_OK;
+}
+
+int trex_model_num_visuals(const TrexModel *m) { return m ? (int)m->host.visual_file.size() : fail(TREX_E_INVALID, "null model"); }
+int trex_model_visual_info(const TrexModel *m, int visual, const char **mesh_file, int *link, double xyz[3], double quat_xyzw[4]) {
+  if (!m) return fail(TREX_E_INVALID, "null model");
+  if (visual < 0 || visual >= (int)m->host.visual_file.size()) return fail(TREX_E_INVALID, "visual index out of range");
+  if (mesh_file) *mesh_file = m->host.visual_file[visual].c_str();
+  if (link) *link = m->host.visual_link[visual];
+  const trex::Tf &t = m->host.visual_origin[visual];
+  if (xyz) { xyz[0] = t.t.x; xyz[1] = t.t.y; xyz[2] = t.t.z; }
+  if (quat_xyzw) trex::matrix_to_quat(t.R, quat_xyzw);
+  return TREX_OK;
+}
+int trex_batch_visual_transforms(TrexBatch *b, float *out_dev, void *stream) {
+  if (check_batch(b)) return TREX_E_INVALID;
+  if (!out_dev) return fail(TREX_E_INVALID, "out is null");
+  if (b->arr.num_visuals == 0) return fail(TREX_E_INVALID, "the model has no <visual> meshes");
+  DeviceGuard guard(b->device);
+  BUF_TRY(out_dev, (size_t)b->n * b->arr.num_visuals * 7 * sizeof(float), "trex_batch_visual_transforms: out");
+  HIP_TRY(trex_launch_link_transforms(b->dmodel, b->arr, b->n, out_dev, (hipStream_t)stream, 1));
   return TREX_OK;
 }
 

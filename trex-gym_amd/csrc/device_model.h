@@ -70,4 +70,7 @@ struct TrexBatchArrays {
   int num_links;
   const int *link_body;   /* [L] body of each URDF link */
   const float *link_tf;   /* [L][12] body<-link transform: rotation row-major (9) + translation (3) */
+  int num_visuals;
+  const int *visual_body; /* [V] body of each <visual> mesh */
+  const float *visual_tf; /* [V][12] body<-mesh transform (link frame in its body x the visual's <origin>) */
 };

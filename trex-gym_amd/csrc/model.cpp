@@ -432,6 +432,11 @@ HostModel load_model(const std::string &urdf_path, const char *collisions_dir, i
     for (size_t l = 0; l < links.size(); l++) m.link_names[l] = links[l].name;
     for (int i = 0; i < nb; i++)
       for (auto &[li, tf] : bodies[i].members) { m.link_body[li] = i; m.link_tf[li] = tf; }
+    for (size_t l = 0; l < links.size(); l++)
+      for (auto &v : links[l].visuals) {
+        m.visual_file.push_back(v.file); m.visual_link.push_back((int)l);
+        m.visual_origin.push_back(v.origin); m.visual_body_tf.push_back(compose(m.link_tf[l], v.origin));
+      }
 
     // observation order = revolute joint names sorted (trex_robot.py:311-314)
     std::vector<std::pair<std::string, int>> named;

@@ -54,6 +54,11 @@ struct HostModel {
   std::vector<std::string> link_names;
   std::vector<int> link_body;
   std::vector<Tf> link_tf;
+  // every <visual> mesh (document order): file name as written in the URDF, its link, its <origin> in the link
+  // frame (what tools/urdf_parsing.py:93-120 calls visual_shapes) and the same in the frame of the link's body
+  std::vector<std::string> visual_file;
+  std::vector<int> visual_link;
+  std::vector<Tf> visual_origin, visual_body_tf;
   std::vector<Vec3> hull_xyz;
   std::vector<double> hull_radius;     // support radius per point: 0 for hull vertices, > 0 for fitted spheres
   std::vector<int> hull_start;

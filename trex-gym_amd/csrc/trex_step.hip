@@ -50,6 +50,16 @@
 #ifndef TREX_STAMPS
 #define TREX_STAMPS 0
 #endif
+// diagnostic variants for scripts/parity_ablation.sh (which round-2 arithmetic shortcut costs what in one-step error)
+#ifndef TREX_ABLATE_EXACT_MATH
+#define TREX_ABLATE_EXACT_MATH 0
+#endif
+#ifndef TREX_ABLATE_EXACT_QUAT
+#define TREX_ABLATE_EXACT_QUAT 0
+#endif
+#ifndef TREX_ABLATE_PLAIN_COMMIT
+#define TREX_ABLATE_PLAIN_COMMIT 0
+#endif
 #ifndef TREX_PRIO_MODE
 #define TREX_PRIO_MODE 1   // 0: no priorities (ablation), 1: the policy described at set_sweep_priority
 #endif
@@ -260,6 +270,9 @@ __device__ __forceinline__ void cross3_acc(const float *a, const float *b, float
 struct Chol6 { float l[15], il[6]; };
 __device__ __forceinline__ constexpr int lidx(int i, int j) { return i * (i - 1) / 2 + j; }
 __device__ __forceinline__ float rsqrt_nr(float s) {
+#if TREX_ABLATE_EXACT_MATH   // diagnostic variant (scripts/parity_ablation.sh): IEEE sqrt and division
+  return 1.0f / sqrtf(s);
+#endif
   const float r0 = __builtin_amdgcn_rsqf(s);
   const float e = __builtin_fmaf(-s * r0, r0, 1.0f);   // 1 - s r0^2
   return __builtin_fmaf(0.5f * r0, e, r0);
@@ -1155,7 +1168,11 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
             U[5] = IA.B[2] * Sa[0] + IA.B[5] * Sa[1] + IA.B[8] * Sa[2];
             const float D = dot3(Sa, U);
             const float rD = __builtin_amdgcn_rcpf(D);
+#if TREX_ABLATE_EXACT_MATH
+            const float invD = 1.0f / D;
+#else
             const float invD = rD * __builtin_fmaf(-D, rD, 2.0f);   // v_rcp_f32 + one Newton step (no IEEE division expansion)
+#endif
             const float u = tau_j - dot3(Sa, pA);
             float Ud[6];
 #pragma unroll
@@ -1841,13 +1858,13 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
       // division: sin(h)/|w| = dt/2 (1 - h^2/6 + h^4/120 - h^6/5040 + h^8/362880)
       const float w2 = dot3(bw, bw), h2 = 0.25f * dt * dt * w2;
       float dq[4];
-      if (h2 < 0.0625f) {
+      if (h2 < 0.0625f && !TREX_ABLATE_EXACT_QUAT) {
         const float sc = 1.f + h2 * (-1.f / 6.f + h2 * (1.f / 120.f + h2 * (-1.f / 5040.f + h2 * (1.f / 362880.f))));
         const float sh = 0.5f * dt * sc;
         dq[0] = bw[0] * sh; dq[1] = bw[1] * sh; dq[2] = bw[2] * sh;
         dq[3] = 1.f + h2 * (-0.5f + h2 * (1.f / 24.f + h2 * (-1.f / 720.f + h2 * (1.f / 40320.f))));
       } else {
-        const float wn = sqrtf(w2), sh = sinf(0.5f * wn * dt) / wn;
+        const float wn = sqrtf(w2), sh = wn > 1e-12f ? sinf(0.5f * wn * dt) / wn : 0.5f * dt;
         dq[0] = bw[0] * sh; dq[1] = bw[1] * sh; dq[2] = bw[2] * sh; dq[3] = cosf(0.5f * wn * dt);
       }
       float o[4];
@@ -2000,7 +2017,8 @@ __global__ void trex_head_kernel(KernelArgs args, float *out) {
 
 // Rollout export: world pose of every URDF link. One 64-thread block per env: lanes < nb walk their
 // body's chain from the base (<= 6 hinges) and park R, p in LDS; then the block strides over the links.
-__global__ __launch_bounds__(64) void trex_link_transforms_kernel(KernelArgs args, float *out) {
+__global__ __launch_bounds__(64) void trex_link_transforms_kernel(KernelArgs args, float *out, int L, const int *frame_body,
+                                                                  const float *frame_tf) {
   __shared__ float bodyR[TL][9], bodyP[TL][3];
   const int env = blockIdx.x;
   const TrexDeviceModel *M = args.model;
@@ -2031,10 +2049,11 @@ __global__ __launch_bounds__(64) void trex_link_transforms_kernel(KernelArgs arg
     for (int c = 0; c < 3; c++) bodyP[t][c] = p[c];
   }
   __syncthreads();
-  const int L = args.arr.num_links;
+  // the frames to export: the URDF link frames (trex_batch_link_transforms) or the <visual> meshes
+  // (trex_batch_visual_transforms), each given by its body and its transform in that body's frame
   for (int l = t; l < L; l += blockDim.x) {
-    const int body = args.arr.link_body[l];
-    const float *tf = args.arr.link_tf + 12 * l;
+    const int body = frame_body[l];
+    const float *tf = frame_tf + 12 * l;
     float R[9], o[3];
     matmul3(bodyR[body], tf, R);
     matvec3(bodyR[body], tf + 9, o);
@@ -2117,9 +2136,11 @@ hipError_t trex_launch_head(const TrexDeviceModel *model, TrexBatchArrays arr, i
   return hipGetLastError();
 }
 
-hipError_t trex_launch_link_transforms(const TrexDeviceModel *model, TrexBatchArrays arr, int n, float *out, hipStream_t stream) {
+hipError_t trex_launch_link_transforms(const TrexDeviceModel *model, TrexBatchArrays arr, int n, float *out, hipStream_t stream,
+                                       int visuals) {
   KernelArgs a{model, arr, n, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, nullptr};
-  hipLaunchKernelGGL(trex_link_transforms_kernel, dim3(n), dim3(64), 0, stream, a, out);
+  if (visuals) hipLaunchKernelGGL(trex_link_transforms_kernel, dim3(n), dim3(64), 0, stream, a, out, arr.num_visuals, arr.visual_body, arr.visual_tf);
+  else hipLaunchKernelGGL(trex_link_transforms_kernel, dim3(n), dim3(64), 0, stream, a, out, arr.num_links, arr.link_body, arr.link_tf);
   return hipGetLastError();
 }
 

@@ -39,6 +39,7 @@ SYMBOLS = [
     "trex_build_id", "trex_batch_step_rows", "trex_batch_reset_rows",
     "trex_batch_set_episode_limit", "trex_batch_get_episode_steps",
     "trex_batch_set_wave_balance", "trex_batch_forget_buffers",
+    "trex_model_num_visuals", "trex_model_visual_info", "trex_batch_visual_transforms",
 ]
 
 _vp = C.c_void_p
@@ -83,6 +84,9 @@ lib.trex_model_fit_hull_primitives.argtypes = [_vp, C.c_int, C.c_double, C.c_int
 lib.trex_model_num_links.argtypes = [_vp]
 lib.trex_model_link_info.argtypes = [_vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
 lib.trex_batch_link_transforms.argtypes = [_vp, _vp, _vp]
+lib.trex_model_num_visuals.argtypes = [_vp]
+lib.trex_model_visual_info.argtypes = [_vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+lib.trex_batch_visual_transforms.argtypes = [_vp, _vp, _vp]
 lib.trex_batch_contact_stats.argtypes = [_vp, _vp, _vp, _vp]
 lib.trex_batch_launch_info.argtypes = [_vp] + [C.POINTER(C.c_int)] * 4
 lib.trex_batch_time_steps.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, C.POINTER(C.c_float)]
@@ -170,6 +174,17 @@ class Model:
             name, body = C.c_char_p(), C.c_int()
             check(lib.trex_model_link_info(self.h, k, C.byref(name), C.byref(body)))
             out.append((name.value.decode(), body.value))
+        return out
+
+    def visuals(self):
+        """[(mesh file, link index, xyz[3], quat_xyzw[4])] of every <visual> mesh, document order
+        (tools/urdf_parsing.py:93-120: UrdfLink.visual_shapes)."""
+        out = []
+        for k in range(lib.trex_model_num_visuals(self.h)):
+            name, link = C.c_char_p(), C.c_int()
+            xyz, quat = (C.c_double * 3)(), (C.c_double * 4)()
+            check(lib.trex_model_visual_info(self.h, k, C.byref(name), C.byref(link), xyz, quat))
+            out.append((name.value.decode(), link.value, np.array(xyz[:]), np.array(quat[:])))
         return out
 
     def use_primitive_collision(self, max_radius=0.2, max_divisions=3, min_points=4):
@@ -321,6 +336,9 @@ class Batch:
 
     def link_transforms(self, out, stream=None):
         check(lib.trex_batch_link_transforms(self.h, self._p(out, "float32", None, "out"), self._stream(stream)))
+
+    def visual_transforms(self, out, stream=None):
+        check(lib.trex_batch_visual_transforms(self.h, self._p(out, "float32", None, "out"), self._stream(stream)))
 
     def set_domain(self, mass_scale=None, friction=None, stream=None):
         n = self.num_envs

@@ -198,6 +198,15 @@ class TrexVecEnv:
         self.batch.link_transforms(out)
         return out
 
+    def visual_transforms(self):
+        """World pose of every <visual> mesh of the URDF, [n, V, 7] = xyz + quaternion xyzw (252 meshes for trex.urdf;
+        `model.visuals()` names them): what a renderer places the meshes with - the table pybullet keeps for
+        getCameraImage (trex_env.py:164-176)."""
+        V = len(self.model.visuals())
+        out = torch.empty(self.num_envs, V, 7, device=self.device)
+        self.batch.visual_transforms(out)
+        return out
+
     def set_domain(self, mass_scale=None, friction=None):
         """Per-env domain randomisation (BASELINE config 5): mass_scale [n, num_bodies], friction [n]."""
         if mass_scale is not None:
