@@ -170,3 +170,13 @@ def test_visual_mesh_table_matches_the_reference_parser(capi):
         np.testing.assert_allclose(tm.quat_to_matrix(quat), tm.quat_to_matrix(g["origin"]["quat_xyzw"]), atol=1e-12)
     name, link = capi.C.c_char_p(), capi.C.c_int()
     assert capi.lib.trex_model_visual_info(m.h, 252, capi.C.byref(name), capi.C.byref(link), None, None) == capi.E_INVALID
+
+
+def test_policy_header_symbols_exported(capi):
+    """include/trex_policy.h (the trainer-side kernels): every declared function is exported by libtrex_hip.so."""
+    import re
+    header = open(os.path.join(ROOT, "include", "trex_policy.h")).read()
+    declared = set(re.findall(r"\b(trex_policy_\w+)\s*\(", header))
+    assert declared == set(capi.POLICY_SYMBOLS)
+    for name in declared:
+        assert hasattr(capi.lib, name), name

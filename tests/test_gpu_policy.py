@@ -1,0 +1,222 @@
+"""The trainer-side HIP kernels (include/trex_policy.h, csrc/policy_step.hip) against the f64 oracle of the PPO2 /
+VecNormalize arithmetic (oracle/ppo_oracle.py - parity unpinned, see its header) and against the same MlpPolicy
+evaluated by plain f32 PyTorch. Tolerances: 1e-5 relative for everything computed in f32 on both sides of a short
+chain (policy outputs, advantages, returns, losses), 1e-10 for the f64 running statistics, and for the parameter
+update 1e-5 of the step size lr (Adam's first steps are +-lr per element whatever the gradient's size)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ppo_oracle as P
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _theta_to_params(kern, theta):
+    """flat [in, out] vector -> the oracle's dict in nn.Sequential naming with [out, in] weights"""
+    th = theta.detach().cpu().double().numpy()
+    out = {}
+    for name, (off, shape) in kern.layout.items():
+        v = th[off:off + math.prod(shape)].reshape(shape)
+        if name == "logstd":
+            out["logstd"] = v
+            continue
+        net, what = name.split(".")
+        k = {"1": 0, "2": 2, "3": 4}[what[1]]
+        out["%s.%d.%s" % (net, k, "weight" if what[0] == "W" else "bias")] = v.T.copy() if what[0] == "W" else v
+    return out
+
+
+def _grads_to_flat(kern, grads):
+    flat = np.zeros(kern.param_count)
+    for name, (off, shape) in kern.layout.items():
+        if name == "logstd":
+            g = grads["logstd"]
+        else:
+            net, what = name.split(".")
+            k = {"1": 0, "2": 2, "3": 4}[what[1]]
+            g = grads["%s.%d.%s" % (net, k, "weight" if what[0] == "W" else "bias")]
+            g = g.T if what[0] == "W" else g
+        flat[off:off + math.prod(shape)] = np.asarray(g).reshape(-1)
+    return flat
+
+
+@pytest.mark.parametrize("n", [4096, 77])
+def test_policy_kernel_matches_f32_torch_and_the_oracle(n):
+    """trex_policy_act: normalise + clip, both MLPs on the matrix cores, sample, log-prob - against MlpPolicy in f32
+    torch at 1e-5 and against the f64 oracle; ragged batch (n not a multiple of the 32-env tile) included."""
+    from trex_gym import _capi
+    from trex_gym.ppo import MlpPolicy
+    torch.manual_seed(1)
+    D, A = 75, 25
+    kern = _capi.Policy(n, D, A, 64, 0)
+    pol = MlpPolicy(kern.layout, kern.param_count, torch.device(DEV))
+    with torch.no_grad():       # away from the special initial point (last layers at gain 0.01, biases 0, logstd 0)
+        pol.theta.add_(0.05 * torch.randn_like(pol.theta))
+    rows = torch.randn(n, 77, device=DEV) * torch.linspace(0.1, 30.0, 77, device=DEV)
+    rows[:, 5] = 1e4            # a column that must clip
+    st = dict(obs_mean=np.linspace(-1, 1, D), obs_var=np.linspace(0.5, 9.0, D), obs_count=100.0, ret_mean=0.0, ret_var=4.0,
+              ret_count=100.0)
+    kern.set_stats(st)
+    noise = torch.randn(n, A, device=DEV)
+    actions, obs_n, act_b = torch.empty(n, A, device=DEV), torch.empty(n, D, device=DEV), torch.empty(n, A, device=DEV)
+    logp, val = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    kern.act(pol.theta, rows, noise, actions, obs_n, act_b, logp, val, clip_obs=10.0)
+    # f32 torch reference of the same op
+    mean32 = torch.tensor(st["obs_mean"], device=DEV, dtype=torch.float32)
+    rstd32 = torch.tensor(1.0 / np.sqrt(st["obs_var"] + 1e-8), device=DEV, dtype=torch.float32)
+    with torch.no_grad():
+        o = ((rows[:, :D] - mean32) * rstd32).clamp(-10.0, 10.0)
+        d = pol.dist(o)
+        a = d.loc + d.scale * noise
+        lp = d.log_prob(a).sum(-1)
+        v = pol.value(o)
+    assert float(o.abs().max()) == 10.0
+    torch.testing.assert_close(obs_n, o, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(actions, a, rtol=1e-5, atol=1e-5)
+    assert torch.equal(act_b, actions)
+    torch.testing.assert_close(val, v, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(logp, lp, rtol=1e-5, atol=2e-4)      # sum of 25 squares of O(1): 1e-5 of its terms
+    # f64 oracle
+    prm = _theta_to_params(kern, pol.theta)
+    o64 = np.clip((rows[:, :D].cpu().double().numpy() - st["obs_mean"]) / np.sqrt(st["obs_var"] + 1e-8), -10, 10)
+    m64, ls64, v64 = P.policy_forward(prm, o64)
+    a64 = P.sample_action(m64, ls64, noise.cpu().double().numpy())
+    np.testing.assert_allclose(actions.cpu().numpy(), a64, rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(val.cpu().numpy(), v64, rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(-logp.cpu().numpy(), P.neglogp(m64, ls64, actions.cpu().double().numpy()), rtol=1e-5, atol=3e-4)
+    # value_only writes nothing but the values
+    val2, keep = torch.empty(n, device=DEV), actions.clone()
+    kern.act(pol.theta, rows, None, None, value_out=val2, value_only=True)
+    assert torch.equal(val2, val) and torch.equal(actions, keep)
+    with pytest.raises(_capi.TrexError):
+        kern.act(pol.theta, rows, noise.cpu(), actions)             # host tensor refused, no GPU fault
+
+
+def test_observe_kernel_is_vecnormalize():
+    """trex_policy_observe over several steps with episode ends == the oracle's VecNormalize (f64 state)."""
+    from trex_gym import _capi
+    n, D = 1000, 75          # ragged: 15.6 workgroups of 64 rows
+    kern = _capi.Policy(n, D, 25, 64, 0)
+    vn = P.VecNormalize(n, D, gamma=0.99)
+    g = torch.Generator(device=DEV).manual_seed(2)
+    rows = torch.empty(n, 77, device=DEV)
+    rows[:, :D] = 5 + 3 * torch.randn(n, D, device=DEV, generator=g)
+    kern.observe(rows, with_reward=False)
+    vn.obs(rows[:, :D].cpu().double().numpy())
+    raw, done, scale = torch.empty(n, device=DEV), torch.empty(n, device=DEV), torch.empty(1, device=DEV)
+    for t in range(6):
+        rows[:, :D] = (5 + t) + (3 + t) * torch.randn(n, D, device=DEV, generator=g)
+        rows[:, D] = -100 * torch.rand(n, device=DEV, generator=g)
+        rows[:, D + 1] = (torch.rand(n, device=DEV, generator=g) < 0.2).float()
+        kern.observe(rows, True, 0.99, raw, done, scale)
+        r64 = rows[:, D].cpu().double().numpy()
+        vn.obs(rows[:, :D].cpu().double().numpy())
+        want_r = vn.reward(r64, rows[:, D + 1].cpu().numpy() != 0)
+        st = kern.get_stats()
+        np.testing.assert_allclose(st["obs_mean"], vn.ob_rms.mean, rtol=1e-10)
+        np.testing.assert_allclose(st["obs_var"], vn.ob_rms.var, rtol=1e-10)
+        assert abs(st["obs_count"] - vn.ob_rms.count) < 1e-9 and abs(st["ret_count"] - vn.ret_rms.count) < 1e-9
+        # the returns are carried in f32 (as VecNormalize's float32 array would be): 1e-6 on their statistics
+        np.testing.assert_allclose(st["ret_mean"], vn.ret_rms.mean, rtol=2e-6)
+        np.testing.assert_allclose(st["ret_var"], vn.ret_rms.var, rtol=2e-6)
+        assert torch.equal(raw, rows[:, D]) and torch.equal(done, rows[:, D + 1])
+        np.testing.assert_allclose(np.clip(raw.cpu().numpy() * scale.item(), -10, 10), want_r, rtol=2e-6)
+        ret = torch.empty(n, device=DEV)
+        kern.get_returns(ret)
+        np.testing.assert_allclose(ret.cpu().numpy(), vn.ret, rtol=1e-5, atol=1e-4)
+        assert (ret[rows[:, D + 1] != 0] == 0).all()
+    assert abs(kern.get_stats()["raw_reward_sum"] - 0.0) > 1.0       # the logging sum moved
+
+
+def test_gae_kernel_matches_the_oracle():
+    from trex_gym import _capi
+    T, n = 32, 513
+    kern = _capi.Policy(n, 75, 25, 64, 0)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    raw = -50 * torch.rand(T, n, device=DEV, generator=g)
+    scale = 0.02 + 0.01 * torch.rand(T, device=DEV, generator=g)
+    scale[3] = 10.0                                               # this step's rewards clip
+    done = (torch.rand(T, n, device=DEV, generator=g) < 0.05).float()
+    val = torch.randn(T + 1, n, device=DEV, generator=g)
+    adv, ret = torch.empty(T, n, device=DEV), torch.empty(T, n, device=DEV)
+    kern.gae(raw, scale, done, val, adv, ret, 0.99, 0.95, 10.0)
+    rew64 = np.clip(raw.cpu().double().numpy() * scale.cpu().double().numpy()[:, None], -10, 10)
+    assert (np.abs(rew64[3]) == 10).any()
+    v64 = val.cpu().double().numpy()
+    a64, r64 = P.gae(rew64, v64[:T], v64[T], done.cpu().double().numpy(), 0.99, 0.95)
+    np.testing.assert_allclose(adv.cpu().numpy(), a64, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ret.cpu().numpy(), r64, rtol=1e-5, atol=1e-5)
+
+
+def test_adam_kernel_is_tensorflows_adam_with_global_norm_clip():
+    from trex_gym import _capi
+    kern = _capi.Policy(64, 75, 25, 64, 0)
+    Pn = kern.param_count
+    g = torch.Generator(device=DEV).manual_seed(4)
+    theta = torch.randn(Pn, device=DEV, generator=g)
+    m, v, norm = torch.zeros(Pn, device=DEV), torch.zeros(Pn, device=DEV), torch.empty(1, device=DEV)
+    p64 = {"w": theta.cpu().double().numpy().copy()}
+    opt = P.Adam(p64, lr=3e-4, epsilon=1e-5)
+    for it, gscale in enumerate((1e-3, 1.0, 1e-6, 0.3)):          # below and above the clip norm of 0.5; tiny gradients
+        grad = gscale * torch.randn(Pn, device=DEV, generator=g)
+        g64 = {"w": grad.cpu().double().numpy().copy()}
+        kern.adam(theta, grad, m, v, lr=3e-4, eps=1e-5, max_grad_norm=0.5, grad_norm_out=norm)
+        gc, n64 = P.clip_by_global_norm(g64, 0.5)
+        p64 = opt.step(p64, gc)
+        assert abs(norm.item() - n64) <= 1e-5 * n64
+        assert float(grad.abs().max()) == 0.0                       # zeroed for the next accumulation
+        np.testing.assert_allclose(theta.cpu().numpy(), p64["w"], rtol=0, atol=1e-5 * 3e-4 * (it + 1) + 2e-7 * np.abs(p64["w"]).max())
+    kern.adam_reset()
+
+
+def test_trainer_rollout_and_one_minibatch_step_match_the_oracle():
+    """PPO.collect on the real env: the recorded rollout (raw rewards, reward scales, dones, values) pushed through the
+    oracle's GAE gives the trainer's advantages / returns; then ONE minibatch step: loss terms and the parameter
+    update against the oracle's analytic gradients + global-norm clip + TF-form Adam."""
+    from trex_gym import trex_train
+    from trex_gym.ppo import PPO
+    env = trex_train.build_environment(256, max_episode_steps=20)
+    agent = PPO(env, nsteps=24, nminibatches=4, noptepochs=1, seed=0)
+    obs, act, logp0, val0, adv, ret, mean_rew = agent.collect()
+    T, n = 24, 256
+    assert agent.b_done.sum() > 0 and math.isfinite(mean_rew) and mean_rew < 0
+    rew64 = np.clip(agent.b_rew.cpu().double().numpy() * agent.b_scale.cpu().double().numpy()[:, None], -10, 10)
+    v64 = agent.b_val.cpu().double().numpy()
+    a64, r64 = P.gae(rew64, v64[:T], v64[T], agent.b_done.cpu().double().numpy(), 0.99, 0.95)
+    np.testing.assert_allclose(adv.cpu().numpy().reshape(T, n), a64, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ret.cpu().numpy().reshape(T, n), r64, rtol=1e-5, atol=1e-5)
+    # the policy kernel's log-prob / value of the rollout == the learner's recomputation at the same parameters
+    with torch.no_grad():
+        d = agent.policy.dist(obs)
+        torch.testing.assert_close(d.log_prob(act).sum(-1), logp0, rtol=1e-5, atol=2e-4)
+        torch.testing.assert_close(agent.policy.value(obs), val0, rtol=1e-5, atol=1e-5)
+    # one minibatch
+    idx = torch.arange(0, T * n, 4, device=DEV)
+    mb = [x.index_select(0, idx) for x in (obs, act, logp0, val0, adv, ret)]
+    # (perturb the old log-probs / values so that ratios leave the clip range and the value clip bites)
+    mb[2] = mb[2] + 0.3 * torch.randn_like(mb[2])
+    mb[3] = mb[3] + 0.3 * torch.randn_like(mb[3])
+    prm = _theta_to_params(agent.kern, agent.policy.theta)
+    theta0 = agent.policy.theta.detach().cpu().double().numpy().copy()
+    out, grads = P.ppo_loss_and_grads(prm, *[x.cpu().double().numpy() for x in mb], cliprange=0.2, ent_coef=0.0, vf_coef=0.5)
+    loss, pg, vf, ent = agent._loss(*mb)
+    assert abs(pg.item() - out["pg_loss"]) <= 1e-5 * max(1.0, abs(out["pg_loss"]))
+    assert abs(vf.item() - out["vf_loss"]) <= 1e-5 * max(1.0, abs(out["vf_loss"]))
+    assert abs(ent.item() - out["entropy"]) <= 1e-5 * abs(out["entropy"])
+    assert ((out["ratio"] > 1.2) | (out["ratio"] < 0.8)).any()
+    loss.backward()
+    gflat = _grads_to_flat(agent.kern, grads)
+    got = agent.policy.grad.detach().cpu().double().numpy()
+    np.testing.assert_allclose(got, gflat, rtol=1e-4, atol=1e-5 * np.abs(gflat).max())
+    agent.kern.adam(agent.policy.theta, agent.policy.grad, agent.adam_m, agent.adam_v, lr=3e-4, eps=1e-5, max_grad_norm=0.5)
+    gc, _ = P.clip_by_global_norm({"w": gflat}, 0.5)
+    want = P.Adam({"w": theta0}, lr=3e-4, epsilon=1e-5).step({"w": theta0}, gc)["w"]
+    step = agent.policy.theta.detach().cpu().double().numpy() - theta0
+    # elements whose gradient is above the f32 noise of the backward pass: the update itself at 1e-5 of lr ... 2 %
+    np.testing.assert_allclose(step, want - theta0, rtol=0, atol=0.02 * 3e-4)
+    big = np.abs(gc["w"]) > 1e-3 * np.abs(gc["w"]).max()
+    np.testing.assert_allclose(step[big], (want - theta0)[big], rtol=1e-3, atol=1e-5 * 3e-4)

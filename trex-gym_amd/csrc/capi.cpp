@@ -11,6 +11,7 @@
 
 #include "../../include/trex_batch.h"
 #include "device_model.h"
+#include "internal.hpp"
 #include "model.hpp"
 
 extern "C" {
@@ -42,8 +43,7 @@ struct TrexBatch {
   std::vector<void *> allocs;
   // caller allocations already validated as memory of this device (base address, bytes known to be good):
   // the hot path pays one hash-free scan of a handful of entries, hipPointerGetAttributes only on a new one
-  struct Seen { const void *p; size_t bytes; };
-  std::vector<Seen> seen;
+  std::vector<TrexSeen> seen;
 };
 
 namespace {
@@ -63,17 +63,7 @@ int hip_fail(hipError_t e, const char *what) {
     if (_e != hipSuccess) return hip_fail(_e, #expr);  \
   } while (0)
 
-struct DeviceGuard {
-  int prev = -1;
-  bool ok;
-  explicit DeviceGuard(int dev) {
-    ok = hipGetDevice(&prev) == hipSuccess && (prev == dev || hipSetDevice(dev) == hipSuccess);
-    if (prev == dev) prev = -1;
-  }
-  ~DeviceGuard() {
-    if (prev >= 0) (void)hipSetDevice(prev);
-  }
-};
+using DeviceGuard = TrexDeviceGuard;
 
 void fill_device_model(const trex::HostModel &h, TrexDeviceModel &d) {
   std::memset(&d, 0, sizeof d);
@@ -183,15 +173,27 @@ void fill_device_model(const trex::HostModel &h, TrexDeviceModel &d) {
 
 int check_batch(const TrexBatch *b) { return b ? TREX_OK : fail(TREX_E_INVALID, "null batch"); }
 
-// A caller-owned buffer must be HIP device (or managed) memory of the batch's device and at least `bytes`
+int check_device_buffer(TrexBatch *b, const void *p, size_t bytes, const char *what) {
+  return trex_check_device_buffer(b->device, b->seen, p, bytes, what);
+}
+#define BUF_TRY(p, bytes, what)                                                  \
+  do {                                                                           \
+    if (int _c = check_device_buffer(b, (p), (size_t)(bytes), (what))) return _c; \
+  } while (0)
+
+}  // namespace
+
+int trex_fail(int code, const std::string &msg) { return fail(code, msg); }
+
+// A caller-owned buffer must be HIP device (or managed) memory of the given device and at least `bytes`
 // long: a host pointer or a short buffer would make the kernel fault the GPU. NULL is accepted where the
 // header says nullable (the caller checks non-nullable arguments first).
-int check_device_buffer(TrexBatch *b, const void *p, size_t bytes, const char *what) {
+int trex_check_device_buffer(int device, std::vector<TrexSeen> &seen, const void *p, size_t bytes, const char *what) {
   if (!p) return TREX_OK;
   // validated ALLOCATIONS of this device: any pointer into one of them with enough room behind it passes without a
   // runtime query (a caller that walks through one large tensor - a [T, N, J] action pool - presents a new pointer
   // every step; hipPointerGetAttributes + hipMemGetAddressRange cost about 20 us)
-  for (const auto &s : b->seen) {
+  for (const auto &s : seen) {
     const char *lo = (const char *)s.p, *q = (const char *)p;
     if (q >= lo && q + bytes <= lo + s.bytes) return TREX_OK;
   }
@@ -204,9 +206,9 @@ int check_device_buffer(TrexBatch *b, const void *p, size_t bytes, const char *w
   }
   if (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged)
     return fail(TREX_E_INVALID, std::string(what) + ": pointer is not device memory");
-  if (at.type == hipMemoryTypeDevice && at.device != b->device)
+  if (at.type == hipMemoryTypeDevice && at.device != device)
     return fail(TREX_E_INVALID, std::string(what) + ": buffer lives on device " + std::to_string(at.device) +
-                                    ", the batch on device " + std::to_string(b->device));
+                                    ", the batch on device " + std::to_string(device));
   void *base = nullptr;
   size_t size = 0;
   const void *lo = p;
@@ -220,16 +222,10 @@ int check_device_buffer(TrexBatch *b, const void *p, size_t bytes, const char *w
   } else {
     (void)hipGetLastError();
   }
-  if (b->seen.size() >= 64) b->seen.erase(b->seen.begin());
-  b->seen.push_back({lo, known});
+  if (seen.size() >= 64) seen.erase(seen.begin());
+  seen.push_back({lo, known});
   return TREX_OK;
 }
-#define BUF_TRY(p, bytes, what)                                                  \
-  do {                                                                           \
-    if (int _c = check_device_buffer(b, (p), (size_t)(bytes), (what))) return _c; \
-  } while (0)
-
-}  // namespace
 
 extern "C" {
 

@@ -42,6 +42,13 @@ SYMBOLS = [
     "trex_model_num_visuals", "trex_model_visual_info", "trex_batch_visual_transforms",
 ]
 
+# every symbol include/trex_policy.h declares (the trainer-side kernels)
+POLICY_SYMBOLS = [
+    "trex_policy_create", "trex_policy_destroy", "trex_policy_param_count", "trex_policy_param_offsets",
+    "trex_policy_get_stats", "trex_policy_set_stats", "trex_policy_get_returns", "trex_policy_observe",
+    "trex_policy_act", "trex_policy_gae", "trex_policy_adam", "trex_policy_adam_reset",
+]
+
 _vp = C.c_void_p
 lib.trex_last_error.restype = C.c_char_p
 lib.trex_build_id.restype = C.c_char_p
@@ -90,6 +97,21 @@ lib.trex_batch_visual_transforms.argtypes = [_vp, _vp, _vp]
 lib.trex_batch_contact_stats.argtypes = [_vp, _vp, _vp, _vp]
 lib.trex_batch_launch_info.argtypes = [_vp] + [C.POINTER(C.c_int)] * 4
 lib.trex_batch_time_steps.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, C.POINTER(C.c_float)]
+
+
+lib.trex_policy_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]
+lib.trex_policy_destroy.argtypes = [_vp]
+lib.trex_policy_destroy.restype = None
+lib.trex_policy_param_count.argtypes = [_vp]
+lib.trex_policy_param_offsets.argtypes = [_vp, C.POINTER(C.c_int)]
+lib.trex_policy_get_stats.argtypes = [_vp, C.POINTER(C.c_double), _vp]
+lib.trex_policy_set_stats.argtypes = [_vp, C.POINTER(C.c_double), _vp]
+lib.trex_policy_get_returns.argtypes = [_vp, _vp, _vp]
+lib.trex_policy_observe.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_float, _vp, _vp, _vp, _vp]
+lib.trex_policy_act.argtypes = [_vp, _vp, _vp, C.c_int, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]
+lib.trex_policy_gae.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_float, C.c_float, C.c_float, _vp]
+lib.trex_policy_adam.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp]
+lib.trex_policy_adam_reset.argtypes = [_vp, _vp]
 
 
 class TrexError(RuntimeError):
@@ -362,3 +384,89 @@ class Batch:
                                         self._p(reward, "float32", n, "reward"), self._p(done, "uint8", n, "done"), int(steps),
                                         self._stream(stream), C.byref(ms)))
         return ms.value
+
+
+class Policy:
+    """Trainer-side kernels of include/trex_policy.h for N envs on one GPU: VecNormalize state + MlpPolicy.step +
+    GAE + Adam. All tensors are torch HIP tensors owned by the caller; the parameter vector is ONE flat f32 tensor."""
+
+    PARAM_NAMES = ["pi.W1", "pi.b1", "pi.W2", "pi.b2", "pi.W3", "pi.b3", "vf.W1", "vf.b1", "vf.W2", "vf.b2", "vf.W3", "vf.b3",
+                   "logstd"]
+
+    def __init__(self, num_envs, obs_dim, act_dim, hidden=64, device=0):
+        self.n, self.D, self.A, self.H, self.device = int(num_envs), int(obs_dim), int(act_dim), int(hidden), int(device)
+        h = _vp()
+        check(lib.trex_policy_create(self.n, self.D, self.A, self.H, self.device, C.byref(h)))
+        self.h = h
+        self.param_count = lib.trex_policy_param_count(h)
+        off = (C.c_int * 13)()
+        check(lib.trex_policy_param_offsets(h, off))
+        D, A, H = self.D, self.A, self.H
+        shapes = [(D, H), (H,), (H, H), (H,), (H, A), (A,), (D, H), (H,), (H, H), (H,), (H, 1), (1,), (A,)]
+        self.layout = {n: (int(o), sh) for n, o, sh in zip(self.PARAM_NAMES, off, shapes)}
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.trex_policy_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _p(self, t, numel, what, dtype="float32"):
+        import torch
+        return _ptr(t, self.device, getattr(torch, dtype), numel, what)
+
+    _stream = staticmethod(Batch._stream)
+
+    def get_stats(self):
+        """dict of VecNormalize's running statistics (host, f64)."""
+        D = self.D
+        buf = (C.c_double * (2 * D + 5))()
+        check(lib.trex_policy_get_stats(self.h, buf, self._stream(None)))
+        a = np.array(buf[:])
+        return dict(obs_mean=a[:D], obs_var=a[D:2 * D], obs_count=a[2 * D], ret_mean=a[2 * D + 1], ret_var=a[2 * D + 2],
+                    ret_count=a[2 * D + 3], raw_reward_sum=a[2 * D + 4])
+
+    def set_stats(self, st):
+        D = self.D
+        a = np.concatenate([np.asarray(st["obs_mean"], float).reshape(D), np.asarray(st["obs_var"], float).reshape(D),
+                            [st["obs_count"], st["ret_mean"], st["ret_var"], st["ret_count"], st.get("raw_reward_sum", 0.0)]])
+        check(lib.trex_policy_set_stats(self.h, (C.c_double * (2 * D + 5))(*a), self._stream(None)))
+
+    def get_returns(self, out):
+        check(lib.trex_policy_get_returns(self.h, self._p(out, self.n, "ret"), self._stream(None)))
+
+    def observe(self, rows, with_reward=True, gamma=0.99, raw_rew_out=None, done_out=None, rew_scale_out=None, stream=None):
+        n = self.n
+        check(lib.trex_policy_observe(self.h, self._p(rows, (n - 1) * rows.shape[1] + self.D + (2 if with_reward else 0), "rows"),
+                                      int(rows.shape[1]), int(bool(with_reward)), float(gamma), self._p(raw_rew_out, n, "raw_rew_out"),
+                                      self._p(done_out, n, "done_out"), self._p(rew_scale_out, 1, "rew_scale_out"),
+                                      self._stream(stream)))
+
+    def act(self, theta, rows, noise, actions, obs_out=None, act_out=None, logp_out=None, value_out=None, clip_obs=10.0,
+            value_only=False, stream=None):
+        n, D, A = self.n, self.D, self.A
+        check(lib.trex_policy_act(self.h, self._p(theta, self.param_count, "theta"), self._p(rows, (n - 1) * rows.shape[1] + D, "rows"),
+                                  int(rows.shape[1]), float(clip_obs), self._p(noise, n * A, "noise"), self._p(actions, n * A, "actions"),
+                                  self._p(obs_out, n * D, "obs_out"), self._p(act_out, n * A, "act_out"),
+                                  self._p(logp_out, n, "logp_out"), self._p(value_out, n, "value_out"), int(bool(value_only)),
+                                  self._stream(stream)))
+
+    def gae(self, raw_rew, rew_scale, done, values, adv, ret, gamma=0.99, lam=0.95, clip_rew=10.0, stream=None):
+        T, n = int(raw_rew.shape[0]), self.n
+        check(lib.trex_policy_gae(self.h, self._p(raw_rew, T * n, "raw_rew"), self._p(rew_scale, T, "rew_scale"),
+                                  self._p(done, T * n, "done"), self._p(values, (T + 1) * n, "values"), self._p(adv, T * n, "adv"),
+                                  self._p(ret, T * n, "ret"), T, float(gamma), float(lam), float(clip_rew), self._stream(stream)))
+
+    def adam(self, theta, grad, m, v, lr=3e-4, beta1=0.9, beta2=0.999, eps=1e-5, max_grad_norm=0.5, grad_norm_out=None, stream=None):
+        P = self.param_count
+        check(lib.trex_policy_adam(self.h, self._p(theta, P, "theta"), self._p(grad, P, "grad"), self._p(m, P, "m"), self._p(v, P, "v"),
+                                   float(lr), float(beta1), float(beta2), float(eps), float(max_grad_norm),
+                                   self._p(grad_norm_out, 1, "grad_norm_out"), self._stream(stream)))
+
+    def adam_reset(self, stream=None):
+        check(lib.trex_policy_adam_reset(self.h, self._stream(stream)))

@@ -1,15 +1,21 @@
 """On-device PPO2 driver for TrexVecEnv (BASELINE config 3).
 
-The reference trains with baselines' ppo2.learn on DummyVecEnv -> VecNormalize
-(trex_train.py:35-63). baselines / TensorFlow are not installed here, so this is an equivalent in
-plain PyTorch that keeps the WHOLE loop in HBM: observations, actions, advantages and the policy
-never leave the GPU, and the env is stepped through step_tensor() (no host sync per step).
+The reference trains with baselines' ppo2.learn on DummyVecEnv -> VecNormalize (trex_train.py:35-63). baselines /
+TensorFlow are not installed here, so this is an equivalent that keeps the WHOLE loop in HBM: observations, actions,
+advantages and the policy never leave the GPU, and the env is stepped through step_tensor() (no host sync per step).
 
-Kept from the reference (trex_train.py:49-61): MlpPolicy (2 x 64 tanh, separate value net, state-
-independent log-std), lam 0.95, gamma 0.99, lr 3e-4, cliprange 0.2, ent_coef 0.0, nminibatches 32,
-VecNormalize-style running normalisation of observations and of discounted returns (clip 10).
-Different on purpose: nsteps (4096 steps x 4096 envs would be 16.7 M samples per batch) and
-noptepochs default to smaller values; both are constructor arguments and are printed by the trainer.
+The per-step caller work - VecNormalize's running statistics, the policy / value MLPs, the Gaussian sample and its
+log-probability - runs in the hand-written HIP kernels of include/trex_policy.h (csrc/policy_step.hip: two launches
+per env step instead of ~30 framework kernels), GAE(lambda) and the optimiser step (global-norm clip + Adam in
+TensorFlow's form, as ppo2 applies it) in one launch each. There is no fallback: without libtrex_hip.so this module
+does not import. PyTorch keeps one job: autograd over the minibatch loss, on parameters that are VIEWS into the flat
+f32 vector the kernels read (weights stored [in, out]).
+
+Kept from the reference (trex_train.py:49-61): MlpPolicy (2 x 64 tanh, separate value net, state-independent
+log-std), lam 0.95, gamma 0.99, lr 3e-4, cliprange 0.2, ent_coef 0.0, nminibatches 32, VecNormalize's running
+normalisation of observations and of discounted returns (clip 10). Different on purpose: nsteps (4096 steps x 4096
+envs would be 16.7 M samples per batch) and noptepochs default to smaller values; both are constructor arguments and
+are printed by the trainer. The arithmetic is restated in f64 by oracle/ppo_oracle.py (tests/test_gpu_policy.py).
 """
 import math
 import time
@@ -17,132 +23,117 @@ import time
 import torch
 from torch import nn
 
-
-class RunningMeanStd:
-    """baselines.common.running_mean_std on device (parallel-variance update)."""
-
-    def __init__(self, shape, device):
-        self.mean = torch.zeros(shape, device=device, dtype=torch.float64)
-        self.var = torch.ones(shape, device=device, dtype=torch.float64)
-        self.count = torch.full((), 1e-4, device=device, dtype=torch.float64)   # tensor: updates are graph-capturable
-
-    def update(self, x):
-        x = x.to(torch.float64).reshape(-1, *self.mean.shape)
-        bm, bv, bc = x.mean(0), x.var(0, unbiased=False), x.shape[0]
-        delta = bm - self.mean
-        tot = self.count + bc
-        m2 = self.var * self.count + bv * bc + delta * delta * self.count * bc / tot
-        self.mean.copy_(self.mean + delta * bc / tot)   # in place: the tensors keep their addresses for graph replay
-        self.var.copy_(m2 / tot)
-        self.count.copy_(tot)
+from . import _capi
 
 
 class MlpPolicy(nn.Module):
-    """baselines MlpPolicy: pi and vf are separate 2 x 64 tanh MLPs, diagonal Gaussian with a free log-std."""
+    """baselines MlpPolicy: pi and vf are separate 2 x 64 tanh MLPs, diagonal Gaussian with a free log-std. The
+    parameters are views into ONE flat f32 vector laid out as include/trex_policy.h says (weights [in, out]); their
+    gradients are views into a second flat vector, so that the optimiser step is one kernel over both."""
 
-    def __init__(self, obs_dim, act_dim, hidden=64):
+    def __init__(self, layout, param_count, device):
         super().__init__()
-        def mlp(out, gain):
-            layers = [nn.Linear(obs_dim, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh(), nn.Linear(hidden, out)]
-            for m, g in zip([layers[0], layers[2], layers[4]], [math.sqrt(2), math.sqrt(2), gain]):
-                nn.init.orthogonal_(m.weight, g)
-                nn.init.zeros_(m.bias)
-            return nn.Sequential(*layers)
-        self.pi = mlp(act_dim, 0.01)
-        self.vf = mlp(1, 1.0)
-        self.logstd = nn.Parameter(torch.zeros(act_dim))
+        self.theta = torch.zeros(param_count, device=device)
+        self.grad = torch.zeros(param_count, device=device)
+        self._names = list(layout)
+        for name, (off, shape) in layout.items():
+            n = math.prod(shape)
+            p = nn.Parameter(self.theta[off:off + n].view(shape))
+            p.grad = self.grad[off:off + n].view(shape)      # autograd accumulates in place: the views stay
+            self.register_parameter(name.replace(".", "_"), p)
+        with torch.no_grad():
+            for net, gain_out in (("pi", 0.01), ("vf", 1.0)):
+                for k, gain in ((1, math.sqrt(2)), (2, math.sqrt(2)), (3, gain_out)):
+                    w = self.p("%s.W%d" % (net, k))
+                    w.copy_(nn.init.orthogonal_(torch.empty(w.shape[1], w.shape[0], device=device), gain).t())
+
+    def p(self, name):
+        return getattr(self, name.replace(".", "_"))
+
+    def _mlp(self, net, x):
+        h = torch.tanh(torch.addmm(self.p(net + ".b1"), x, self.p(net + ".W1")))
+        h = torch.tanh(torch.addmm(self.p(net + ".b2"), h, self.p(net + ".W2")))
+        return torch.addmm(self.p(net + ".b3"), h, self.p(net + ".W3"))
+
+    def mean(self, obs):
+        return self._mlp("pi", obs)
+
+    @property
+    def logstd(self):
+        return self.p("logstd")
 
     def dist(self, obs):
-        return torch.distributions.Normal(self.pi(obs), self.logstd.exp(), validate_args=False)   # the check syncs: not capturable
+        return torch.distributions.Normal(self.mean(obs), self.logstd.exp(), validate_args=False)   # the check syncs: not capturable
 
     def value(self, obs):
-        return self.vf(obs).squeeze(-1)
+        return self._mlp("vf", obs).squeeze(-1)
 
 
 class PPO:
     def __init__(self, env, nsteps=32, nminibatches=32, noptepochs=4, gamma=0.99, lam=0.95, lr=3e-4,
                  cliprange=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, clip_obs=10.0, clip_rew=10.0,
                  seed=0, use_graphs=False):
-        """use_graphs: capture the whole nsteps rollout (policy + env step + normalisation) and one
-        minibatch update as HIP graphs and replay them - the env step launches nothing but stream-ordered
-        kernels, so it is capture-safe (tests/test_gpu_invariants.py)."""
+        """use_graphs: capture the whole nsteps rollout (policy kernel + env step + statistics kernel per step) and
+        one epoch of minibatch updates as HIP graphs and replay them - everything launched is stream-ordered, so it
+        is capture-safe (tests/test_gpu_invariants.py)."""
         self.env = env
         self.dev = env.device
         self.nsteps, self.nminibatches, self.noptepochs = nsteps, nminibatches, noptepochs
-        self.gamma, self.lam, self.cliprange = gamma, lam, cliprange
+        self.gamma, self.lam, self.cliprange, self.lr = gamma, lam, cliprange, lr
         self.ent_coef, self.vf_coef, self.max_grad_norm = ent_coef, vf_coef, max_grad_norm
         self.clip_obs, self.clip_rew = clip_obs, clip_rew
         torch.manual_seed(seed)
         n, od, ad = env.num_envs, env.observation_space.shape[0], env.action_space.shape[0]
-        self.policy = MlpPolicy(od, ad).to(self.dev)
+        self.kern = _capi.Policy(n, od, ad, 64, self.dev.index)       # VecNormalize state + the kernels
+        self.policy = MlpPolicy(self.kern.layout, self.kern.param_count, self.dev)
+        self.adam_m = torch.zeros_like(self.policy.theta)
+        self.adam_v = torch.zeros_like(self.policy.theta)
         self.use_graphs = use_graphs
-        self.opt = torch.optim.Adam(self.policy.parameters(), lr=lr, eps=1e-5, capturable=use_graphs)
         self._rollout_graph = self._update_graph = None
-        self.obs_rms = RunningMeanStd((od,), self.dev)
-        self.ret_rms = RunningMeanStd((), self.dev)
-        self.ret = torch.zeros(n, device=self.dev)
-        self.obs = self._norm_obs(env.reset_tensor().clone(), update=True)
         self.total_env_steps = 0
         T = nsteps
+        self.noise = torch.empty(T, n, ad, device=self.dev)
+        self.actions = torch.empty(n, ad, device=self.dev)
         self.b_obs = torch.empty(T, n, od, device=self.dev)
         self.b_act = torch.empty(T, n, ad, device=self.dev)
         self.b_logp = torch.empty(T, n, device=self.dev)
         self.b_val = torch.empty(T + 1, n, device=self.dev)
-        self.b_rew = torch.empty(T, n, device=self.dev)
+        self.b_rew = torch.empty(T, n, device=self.dev)          # RAW rewards; GAE applies scale[t] and the clip
+        self.b_scale = torch.empty(T, device=self.dev)
         self.b_done = torch.empty(T, n, device=self.dev)
         self.b_adv = torch.empty(T, n, device=self.dev)
         self.b_ret = torch.empty(T, n, device=self.dev)
-        self.raw_rew = torch.zeros((), device=self.dev, dtype=torch.float64)
+        self._raw_sum = 0.0
+        env.reset_tensor()
+        self.kern.observe(env.rows, with_reward=False)           # VecNormalize.reset: the statistics see the first obs
 
-    # VecNormalize (trex_train.py:45)
-    def _norm_obs(self, obs, update):
-        if update:
-            self.obs_rms.update(obs)
-        o = (obs.to(torch.float64) - self.obs_rms.mean) / torch.sqrt(self.obs_rms.var + 1e-8)
-        return o.clamp(-self.clip_obs, self.clip_obs).to(torch.float32)
-
-    def _norm_rew(self, rew, done):
-        self.ret.mul_(self.gamma).add_(rew)     # in place: a captured rollout must carry the returns over replays
-        self.ret_rms.update(self.ret)
-        r = (rew.to(torch.float64) / torch.sqrt(self.ret_rms.var + 1e-8)).clamp(-self.clip_rew, self.clip_rew)
-        self.ret.masked_fill_(done, 0.0)
-        return r.to(torch.float32)
+    @property
+    def obs(self):
+        """The normalised observation the policy saw at the last step of the last rollout (diagnostics)."""
+        return self.b_obs[-1]
 
     @torch.no_grad()
     def _rollout(self):
-        """nsteps env steps with the current policy + GAE, everything into the preallocated buffers."""
-        T = self.nsteps
-        self.raw_rew.zero_()
+        """nsteps env steps with the current policy + GAE, everything into the preallocated buffers. Per step: ONE
+        policy launch (normalise, both MLPs on the matrix cores, sample, log-prob), the env's step launch, ONE
+        statistics launch (VecNormalize)."""
+        T, env, k, th = self.nsteps, self.env, self.kern, self.policy.theta
+        self.noise.normal_()
         for t in range(T):
-            d = self.policy.dist(self.obs)
-            a = d.loc + d.scale * torch.randn_like(d.loc)   # torch.normal(mean, std) checks std on the host: not capturable
-            self.b_obs[t].copy_(self.obs); self.b_act[t].copy_(a)
-            self.b_logp[t].copy_(d.log_prob(a).sum(-1)); self.b_val[t].copy_(self.policy.value(self.obs))
-            obs, rew, done = self.env.step_tensor(a)   # the env clips to the joint limits (trex_env.py:147)
-            self.raw_rew += rew.double().mean()
-            self.b_rew[t].copy_(self._norm_rew(rew, done))
-            self.b_done[t].copy_(done.float())
-            self.obs.copy_(self._norm_obs(obs, update=True))
-        self.b_val[T].copy_(self.policy.value(self.obs))
-        last = torch.zeros_like(self.b_val[0])
-        for t in reversed(range(T)):
-            nonterm = 1.0 - self.b_done[t]
-            delta = self.b_rew[t] + self.gamma * self.b_val[t + 1] * nonterm - self.b_val[t]
-            last = delta + self.gamma * self.lam * nonterm * last
-            self.b_adv[t].copy_(last)
+            k.act(th, env.rows, self.noise[t], self.actions, self.b_obs[t], self.b_act[t], self.b_logp[t], self.b_val[t],
+                  clip_obs=self.clip_obs)
+            env.step_tensor(self.actions)       # the env clips to the joint limits (trex_env.py:147)
+            k.observe(env.rows, True, self.gamma, self.b_rew[t], self.b_done[t], self.b_scale[t:t + 1])
+        k.act(th, env.rows, None, None, value_out=self.b_val[T], clip_obs=self.clip_obs, value_only=True)
+        k.gae(self.b_rew, self.b_scale, self.b_done, self.b_val, self.b_adv, self.b_ret, self.gamma, self.lam, self.clip_rew)
 
     @torch.no_grad()
     def collect(self):
         T, n = self.nsteps, self.env.num_envs
+        if len(getattr(self.env, "_row_blocks", [0])) != 1:
+            raise ValueError("the trainer reads env.rows in place: TrexVecEnv(row_buffers=1)")
         if self.use_graphs:
             if self._rollout_graph is None:
-                # the GEMM library sets itself up on the first call of a shape, which a capturing stream refuses:
-                # one policy evaluation outside the capture (no env step, no state change)
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    self.policy.dist(self.obs); self.policy.value(self.obs)
-                torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
                 self._rollout_graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._rollout_graph):
@@ -152,12 +143,13 @@ class PPO:
             self._rollout()
         self.total_env_steps += T * n
         flat = lambda x: x.reshape(T * n, *x.shape[2:])
-        torch.add(self.b_adv, self.b_val[:T], out=self.b_ret)   # (a persistent buffer: the captured update reads it in place)
+        raw = self.kern.get_stats()["raw_reward_sum"]            # (the one host read-back per rollout)
+        mean_rew, self._raw_sum = (raw - self._raw_sum) / (T * n), raw
         return (flat(self.b_obs), flat(self.b_act), flat(self.b_logp), flat(self.b_val[:T]), flat(self.b_adv), flat(self.b_ret),
-                (self.raw_rew / T).item())
+                mean_rew)
 
-    def _minibatch_step(self, obs, act, logp0, val0, adv, ret):
-        a = (adv - adv.mean()) / (adv.std() + 1e-8)
+    def _loss(self, obs, act, logp0, val0, adv, ret):
+        a = (adv - adv.mean()) / (adv.std(unbiased=False) + 1e-8)       # numpy's std: population
         d = self.policy.dist(obs)
         logp = d.log_prob(act).sum(-1)
         ratio = (logp - logp0).exp()
@@ -166,11 +158,13 @@ class PPO:
         vclip = val0 + (v - val0).clamp(-self.cliprange, self.cliprange)
         vf = 0.5 * torch.max((v - ret) ** 2, (vclip - ret) ** 2).mean()
         ent = d.entropy().sum(-1).mean()
-        loss = pg - self.ent_coef * ent + self.vf_coef * vf
-        self.opt.zero_grad(set_to_none=False)
-        loss.backward()
-        nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
-        self.opt.step()
+        return pg - self.ent_coef * ent + self.vf_coef * vf, pg, vf, ent
+
+    def _minibatch_step(self, obs, act, logp0, val0, adv, ret):
+        loss, pg, vf, ent = self._loss(obs, act, logp0, val0, adv, ret)
+        loss.backward()          # accumulates into the flat gradient vector (zeroed by the optimiser kernel)
+        self.kern.adam(self.policy.theta, self.policy.grad, self.adam_m, self.adam_v, lr=self.lr, eps=1e-5,
+                       max_grad_norm=self.max_grad_norm)
         return pg.detach(), vf.detach(), ent.detach()
 
     def _epoch(self, srcs, N, mb):
@@ -189,11 +183,10 @@ class PPO:
         N = obs.shape[0]
         mb = N // self.nminibatches
         if self.use_graphs:
-            # ONE graph per epoch (a permutation + all its minibatch steps, about 2000 nodes): replaying a graph per
-            # minibatch left the update launch-bound - the 60 small kernels of a step take a third of its replay
+            # ONE graph per epoch (a permutation + all its minibatch steps)
             if self._update_graph is None:
                 self._srcs = srcs              # views of the persistent rollout buffers: same addresses every iteration
-                keep = [p.detach().clone() for p in self.policy.parameters()]
+                keep = self.policy.theta.clone()
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):      # warm-up outside the capture (library set-up, autograd buffers)
@@ -202,12 +195,9 @@ class PPO:
                     torch.rand(N, device=self.dev).argsort()
                 torch.cuda.current_stream().wait_stream(side)
                 with torch.no_grad():              # undo the warm-up: same parameters and a fresh Adam state
-                    for p, k in zip(self.policy.parameters(), keep):
-                        p.copy_(k)
-                    for st in self.opt.state.values():
-                        for v in st.values():
-                            if torch.is_tensor(v):
-                                v.zero_()
+                    self.policy.theta.copy_(keep)
+                    self.adam_m.zero_(); self.adam_v.zero_(); self.policy.grad.zero_()
+                    self.kern.adam_reset()
                 torch.cuda.synchronize()
                 self._update_graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._update_graph):

@@ -45,8 +45,9 @@ def train(env, num_timesteps, seed, nsteps=32, noptepochs=None, save_path=None, 
            hp["noptepochs"]))
     hist = agent.learn(num_timesteps, log=log)
     if save_path:
-        torch.save({"policy": agent.policy.state_dict(), "obs_mean": agent.obs_rms.mean, "obs_var": agent.obs_rms.var},
-                   save_path)
+        st = agent.kern.get_stats()     # VecNormalize's running statistics travel with the weights (trex_train.py:93-99 restores both)
+        torch.save({"theta": agent.policy.theta, "layout": agent.kern.layout, "obs_mean": torch.tensor(st["obs_mean"]),
+                    "obs_var": torch.tensor(st["obs_var"]), "ret_var": float(st["ret_var"])}, save_path)
     return agent, hist
 
 
