@@ -202,7 +202,8 @@ def test_trainer_rollout_and_one_minibatch_step_match_the_oracle():
     mb[3] = mb[3] + 0.3 * torch.randn_like(mb[3])
     prm = _theta_to_params(agent.kern, agent.policy.theta)
     theta0 = agent.policy.theta.detach().cpu().double().numpy().copy()
-    out, grads = P.ppo_loss_and_grads(prm, *[x.cpu().double().numpy() for x in mb], cliprange=0.2, ent_coef=0.0, vf_coef=0.5)
+    h = [x.cpu().double().numpy() for x in mb]
+    out, grads = P.ppo_loss_and_grads(prm, h[0], h[1], -h[2], h[3], h[4], h[5], cliprange=0.2, ent_coef=0.0, vf_coef=0.5)   # (-logp = neglogp)
     loss, pg, vf, ent = agent._loss(*mb)
     assert abs(pg.item() - out["pg_loss"]) <= 1e-5 * max(1.0, abs(out["pg_loss"]))
     assert abs(vf.item() - out["vf_loss"]) <= 1e-5 * max(1.0, abs(out["vf_loss"]))

@@ -8,13 +8,13 @@
 //                    workgroup, merged IN FIXED ORDER by the last workgroup to end: deterministic) -> Chan's parallel
 //                    update of the running mean / variance (f64 state, as numpy's in VecNormalize), f32 mean / rstd
 //                    for the policy kernel; ret = ret*gamma + rew; ret[done] = 0.
-//   act_kernel       one workgroup = 32 envs x 2 waves (policy net, value net). The normalised observation tile is
-//                    staged in LDS; the 75 -> 64 -> 64 -> {25, 1} tanh MLPs run on the matrix cores with
+//   act_kernel       one workgroup = 2 tiles of 32 envs x 2 waves (policy net, value net). The parameter vector (84 KB)
+//                    and the normalised observation tiles are staged in LDS; the 75 -> 64 -> 64 -> {25, 1} tanh MLPs run on the matrix cores with
 //                    v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: exact f32, the dense contraction of this path)
 //                    in the TRANSPOSED form H^T = W^T X^T: the result tile has the env on the lane and the neurons in
 //                    the 16 accumulator registers, which is exactly the B operand of the next layer's MFMA - the
 //                    activations never leave the registers (no LDS round trip, no barrier between layers).
-//                    Weights are read [in][out] from the flat parameter vector: 32 consecutive floats per half wave.
+//                    Weights are stored [in][out]: an A operand is 32 consecutive floats per half wave.
 //
 // plus the rollout's GAE(lambda) and the optimiser step (global-norm clip + TF-form Adam) as one launch each.
 // The arithmetic is the one restated by oracle/ppo_oracle.py; tests/test_gpu_policy.py compares the two.
@@ -57,6 +57,16 @@ __host__ __device__ inline Layout make_layout(int D, int A) {
   return l;
 }
 
+// tanh in ~10 instructions, |error| <= 2e-7 absolute (libm's tanhf expands to ~50 with branches; the policy step
+// evaluates 128 per lane): 1 - 2 / (exp(2|x|) + 1) away from 0, the odd series below |x| = 0.1 where that form cancels
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float ax = fabsf(x), x2 = x * x;
+  const float e = __builtin_amdgcn_exp2f(ax * 2.885390081777927f);           // exp(2|x|); inf for large |x| -> t = 1
+  const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+  const float p = x * (1.0f + x2 * (-0.3333333333f + x2 * (0.1333333333f + x2 * (-0.05396825397f))));
+  return ax < 0.1f ? p : copysignf(t, x);
+}
+
 // row of accumulator register `reg` on a lane of half h = lane >> 5 (C/D layout of the 32x32 MFMA forms)
 __device__ __forceinline__ constexpr int rowmap(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
@@ -71,9 +81,8 @@ struct ActArgs {
 
 // hidden layer in transposed form: out^T[32 u + row][env] = b[..] + sum_k W[k][32 u + row] * in^T[k][env], in^T given as
 // two accumulator tiles (k = 32 t + rowmap(s, h) sits in register s of tile t on the lanes of half h): the B operand
-// of MFMA step (t, s) is the lane's OWN register, and the A operand carries the matching k.
-__device__ __forceinline__ void hidden_layer(const float *__restrict__ W, const float *__restrict__ bias, const f32x16 (&in)[2],
-                                             f32x16 (&out)[2], int col, int h) {
+// of MFMA step (t, s) is the lane's OWN register, and the A operand (from the LDS copy of W) carries the matching k.
+__device__ __forceinline__ void hidden_layer(const float *W, const float *bias, const f32x16 (&in)[2], f32x16 (&out)[2], int col, int h) {
 #pragma unroll
   for (int u = 0; u < 2; u++) {
 #pragma unroll
@@ -95,33 +104,69 @@ __device__ __forceinline__ void hidden_layer(const float *__restrict__ W, const 
 #pragma unroll
   for (int u = 0; u < 2; u++) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) out[u][r] = tanhf(out[u][r]);
+    for (int r = 0; r < 16; r++) out[u][r] = tanh_fast(out[u][r]);
   }
 }
 
-__global__ __launch_bounds__(128) void act_kernel(ActArgs g) {
-  __shared__ float X[TILE][MAXD + 1];   // normalised, clipped observations of the tile (+ zero pad column)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // wave 0: policy net, wave 1: value net
-  const int e0 = blockIdx.x * TILE;
+// One workgroup = 4 waves = 2 tiles of 32 envs x {policy net, value net}. The whole parameter vector (21 k floats,
+// 84 KB) is copied to LDS once per workgroup with 16-byte loads that are all in flight together - read from L2 inside
+// the MFMA loops, every A operand was a dependent round trip of its own (32 us per launch; 172 MFMAs per wave).
+constexpr int ACT_TILES = 2;
+__global__ __launch_bounds__(256) void act_kernel(ActArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int net = wave & 1, tile = wave >> 1;          // net 0: policy, 1: value
   const int D = g.lay.D, A = g.lay.A;
   const int Dp = (D + 1) & ~1;          // K of the first layer, padded to the MFMA's k = 2
-  // ---- stage the tile: normalise, clip, keep a copy for the rollout buffer
-  for (int idx = tid; idx < TILE * Dp; idx += 128) {
-    const int i = idx / Dp, k = idx - i * Dp, e = e0 + i;
-    float x = 0.f;
-    if (k < D && e < g.n) {
-      x = (g.rows[(size_t)e * g.row_stride + k] - g.norm[k]) * g.norm[D + k];
-      x = fminf(fmaxf(x, -g.clip_obs), g.clip_obs);
-      if (g.obs_out && !g.value_only) g.obs_out[(size_t)e * D + k] = x;
+  float *th = lds;                                       // [count] parameters
+  float *Xall = lds + ((g.lay.count + 3) & ~3);          // [ACT_TILES][TILE][MAXD + 1] normalised observations (+ zero pad)
+  {
+    // (8 loads per thread in flight per trip: left as a plain loop, every 16-byte load waited for its own round trip)
+    const float4 *src = reinterpret_cast<const float4 *>(g.theta);
+    float4 *dst = reinterpret_cast<float4 *>(th);
+    const int n4 = g.lay.count >> 2;
+    for (int i0 = tid; i0 < n4; i0 += 256 * 8) {
+      float4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int i = i0 + 256 * u; t[u] = src[i < n4 ? i : 0]; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int i = i0 + 256 * u; if (i < n4) dst[i] = t[u]; }
     }
-    X[i][k] = x;
+    for (int i = (n4 << 2) + tid; i < g.lay.count; i += 256) th[i] = g.theta[i];
+  }
+  // ---- stage the tiles: normalise, clip, keep a copy for the rollout buffer
+  const int eb = blockIdx.x * (ACT_TILES * TILE);
+  for (int idx0 = tid; idx0 < ACT_TILES * TILE * Dp; idx0 += 256 * 4) {
+    float raw[4], mean[4], rstd[4];
+    int ii[4], kk[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int idx = idx0 + 256 * u;
+      ii[u] = idx / Dp; kk[u] = idx - ii[u] * Dp;
+      ok[u] = idx < ACT_TILES * TILE * Dp && kk[u] < D && eb + ii[u] < g.n;
+      const int kc = kk[u] < D ? kk[u] : 0;
+      raw[u] = ok[u] ? g.rows[(size_t)(eb + ii[u]) * g.row_stride + kc] : 0.f;
+      mean[u] = g.norm[kc]; rstd[u] = g.norm[D + kc];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (idx0 + 256 * u >= ACT_TILES * TILE * Dp) continue;
+      float x = 0.f;
+      if (ok[u]) {
+        x = fminf(fmaxf((raw[u] - mean[u]) * rstd[u], -g.clip_obs), g.clip_obs);
+        if (g.obs_out && !g.value_only) g.obs_out[(size_t)(eb + ii[u]) * D + kk[u]] = x;
+      }
+      Xall[ii[u] * (MAXD + 1) + kk[u]] = x;
+    }
   }
   __syncthreads();
-  if (g.value_only && wave == 0) return;
+  if (g.value_only && net == 0) return;
+  const float *X = Xall + tile * TILE * (MAXD + 1);
+  const int e0 = eb + tile * TILE;
   const int col = lane & 31, h = lane >> 5;
-  const float *th = g.theta;
-  const float *W1 = th + (wave ? g.lay.vW1 : g.lay.pW1), *b1 = th + (wave ? g.lay.vb1 : g.lay.pb1);
-  const float *W2 = th + (wave ? g.lay.vW2 : g.lay.pW2), *b2 = th + (wave ? g.lay.vb2 : g.lay.pb2);
+  const float *W1 = th + (net ? g.lay.vW1 : g.lay.pW1), *b1 = th + (net ? g.lay.vb1 : g.lay.pb1);
+  const float *W2 = th + (net ? g.lay.vW2 : g.lay.pW2), *b2 = th + (net ? g.lay.vb2 : g.lay.pb2);
   // ---- layer 1: h1^T = tanh(W1^T x^T + b1); B operand = the observation of env `col` from LDS
   f32x16 h1[2], h2[2];
 #pragma unroll
@@ -129,9 +174,10 @@ __global__ __launch_bounds__(128) void act_kernel(ActArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; r++) h1[u][r] = b1[32 * u + rowmap(r, h)];
   }
+#pragma unroll 4
   for (int kk = 0; kk < Dp; kk += 2) {
     const int k = kk + h;
-    const float b = X[col][k];                       // (k = D on the pad column: 0)
+    const float b = X[col * (MAXD + 1) + k];         // (k = D on the pad column: 0)
     const int kc = k < D ? k : D - 1;                // (its weight row does not exist: any finite value, times 0)
 #pragma unroll
     for (int u = 0; u < 2; u++) {
@@ -142,12 +188,12 @@ __global__ __launch_bounds__(128) void act_kernel(ActArgs g) {
 #pragma unroll
   for (int u = 0; u < 2; u++) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) h1[u][r] = tanhf(h1[u][r]);
+    for (int r = 0; r < 16; r++) h1[u][r] = tanh_fast(h1[u][r]);
   }
   // ---- layer 2, activations from registers
   hidden_layer(W2, b2, h1, h2, col, h);
   const int e = e0 + col;
-  if (wave == 1) {
+  if (net == 1) {
     // ---- value head: one output; every lane sums its 32 neurons, the two halves of an env meet by a swap
     const float *w = th + g.lay.vW3;
     float v = 0.f;
@@ -209,50 +255,92 @@ struct ObserveArgs {
   float gamma, epsilon;
 };
 
-__global__ __launch_bounds__(128) void observe_kernel(ObserveArgs g) {
-  const int tid = threadIdx.x, D = g.D, G = gridDim.x;
-  const int r0 = blockIdx.x * OBS_ROWS, r1 = min(r0 + OBS_ROWS, g.n);
-  // thread c < D: observation column c. thread D: the discounted returns. thread D + 1: the raw rewards (logging).
-  // Sums are taken about the RUNNING mean (a shift that every workgroup knows): no cancellation in the variance.
-  if (tid < D) {
-    const double shift = g.stats[tid];
-    double s = 0.0, ss = 0.0;
-    for (int r = r0; r < r1; r++) {
-      const double x = (double)g.rows[(size_t)r * g.row_stride + tid] - shift;
-      s += x; ss += x * x;
-    }
-    double *p = g.partial + ((size_t)blockIdx.x * (D + 2) + tid) * 2;
-    p[0] = s; p[1] = ss;
-  } else if (tid == D && g.with_reward) {
-    const double shift = g.stats[2 * D + 1];
-    double s = 0.0, ss = 0.0, sr = 0.0;
-    for (int r = r0; r < r1; r++) {
-      const float rew = g.rows[(size_t)r * g.row_stride + D], done = g.rows[(size_t)r * g.row_stride + D + 1];
-      const float ret = g.ret[r] * g.gamma + rew;          // VecNormalize: ret = ret * gamma + rews (f32, as numpy's array)
-      const double x = (double)ret - shift;
-      s += x; ss += x * x; sr += (double)rew;
-      g.ret[r] = done != 0.f ? 0.f : ret;                  // ... ret[news] = 0 after the statistics saw it
-      if (g.raw_rew_out) g.raw_rew_out[r] = rew;
-      if (g.done_out) g.done_out[r] = done;
-    }
-    double *p = g.partial + ((size_t)blockIdx.x * (D + 2) + D) * 2;
-    p[0] = s; p[1] = ss; p[2] = sr; p[3] = 0.0;
-  }
-  // ---- the last workgroup to end merges the partials, in workgroup order
+// One workgroup = OBS_ROWS rows x 4 row groups of 128 threads (thread c of a group: column c); every thread takes 8 rows
+// per trip with the 8 loads in flight together. (Version 1 walked 64 rows one dependent load after the other and merged
+// 64 partials the same way: 48 us per launch.)
+constexpr int OBS_GROUPS = 4;
+__global__ __launch_bounds__(128 * OBS_GROUPS) void observe_kernel(ObserveArgs g) {
+  __shared__ double red[OBS_GROUPS][128][3];
   __shared__ bool last;
+  const int tid = threadIdx.x, c = tid & 127, grp = tid >> 7, D = g.D, G = gridDim.x;
+  const int per = OBS_ROWS / OBS_GROUPS;
+  const int r0 = blockIdx.x * OBS_ROWS + grp * per, r1 = min(r0 + per, g.n);
+  // thread c < D: observation column c. thread D: the discounted returns (+ the raw rewards, for logging).
+  // Sums are taken about the RUNNING mean (a shift that every workgroup knows): no cancellation in the variance.
+  double s = 0.0, ss = 0.0, sr = 0.0;
+  if (c < D) {
+    const double shift = g.stats[c];
+    for (int r = r0; r < r1; r += 8) {
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) x[u] = r + u < r1 ? g.rows[(size_t)(r + u) * g.row_stride + c] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (r + u < r1) { const double d = (double)x[u] - shift; s += d; ss += d * d; }
+    }
+  } else if (c == D && g.with_reward) {
+    const double shift = g.stats[2 * D + 1];
+    for (int r = r0; r < r1; r += 8) {
+      float rew[8], done[8], ret[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const bool ok = r + u < r1;
+        rew[u] = ok ? g.rows[(size_t)(r + u) * g.row_stride + D] : 0.f;
+        done[u] = ok ? g.rows[(size_t)(r + u) * g.row_stride + D + 1] : 0.f;
+        ret[u] = ok ? g.ret[r + u] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (r + u < r1) {
+          const float nr = ret[u] * g.gamma + rew[u];         // VecNormalize: ret = ret * gamma + rews (f32, as numpy's array)
+          const double d = (double)nr - shift;
+          s += d; ss += d * d; sr += (double)rew[u];
+          g.ret[r + u] = done[u] != 0.f ? 0.f : nr;           // ... ret[news] = 0 after the statistics saw it
+          if (g.raw_rew_out) g.raw_rew_out[r + u] = rew[u];
+          if (g.done_out) g.done_out[r + u] = done[u];
+        }
+    }
+  }
+  red[grp][c][0] = s; red[grp][c][1] = ss; red[grp][c][2] = sr;
+  __syncthreads();
+  if (grp == 0 && c <= D) {     // the row groups of this workgroup, in order
+    double a = 0.0, b = 0.0, d = 0.0;
+#pragma unroll
+    for (int q = 0; q < OBS_GROUPS; q++) { a += red[q][c][0]; b += red[q][c][1]; d += red[q][c][2]; }
+    double *p = g.partial + ((size_t)blockIdx.x * (D + 2) + c) * 2;
+    p[0] = a; p[1] = b;
+    if (c == D) { p[2] = d; p[3] = 0.0; }
+  }
+  // ---- the last workgroup to end merges the partials, in workgroup order (fixed: deterministic)
   __threadfence();
   __syncthreads();
   if (tid == 0) last = atomicAdd(g.counter, 1u) == (unsigned)(G - 1);
   __syncthreads();
   if (!last) return;
   __threadfence();
-  if (tid < D || (tid == D && g.with_reward)) {
-    double s = 0.0, ss = 0.0;
-    for (int w = 0; w < G; w++) {
-      const double *p = g.partial + ((size_t)w * (D + 2) + tid) * 2;
-      s += p[0]; ss += p[1];
+  // row group q sums the workgroups q, q + 4, ... (8 loads in flight per trip), then group 0 adds the four in order
+  s = 0.0; ss = 0.0; sr = 0.0;
+  if (c <= D) {
+    for (int w = grp; w < G; w += 8 * OBS_GROUPS) {
+      double a[8], b[8], d[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int wu = w + u * OBS_GROUPS;
+        const double *p = g.partial + ((size_t)(wu < G ? wu : 0) * (D + 2) + c) * 2;
+        a[u] = wu < G ? p[0] : 0.0; b[u] = wu < G ? p[1] : 0.0; d[u] = (wu < G && c == D) ? p[2] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) { s += a[u]; ss += b[u]; sr += d[u]; }
     }
-    const int im = tid < D ? tid : 2 * D + 1, iv = tid < D ? D + tid : 2 * D + 2, ic = tid < D ? 2 * D : 2 * D + 3;
+  }
+  __syncthreads();
+  red[grp][c][0] = s; red[grp][c][1] = ss; red[grp][c][2] = sr;
+  __syncthreads();
+  if (grp == 0 && (c < D || (c == D && g.with_reward))) {
+    s = 0.0; ss = 0.0; sr = 0.0;
+#pragma unroll
+    for (int q = 0; q < OBS_GROUPS; q++) { s += red[q][c][0]; ss += red[q][c][1]; sr += red[q][c][2]; }
+    const int im = c < D ? c : 2 * D + 1, iv = c < D ? D + c : 2 * D + 2, ic = c < D ? 2 * D : 2 * D + 3;
     const double mean = g.stats[im], var = g.stats[iv], count = g.stats[ic];
     const double bc = (double)g.n;
     const double bm_rel = s / bc;                       // batch mean relative to the running mean = "delta"
@@ -261,15 +349,13 @@ __global__ __launch_bounds__(128) void observe_kernel(ObserveArgs g) {
     const double m2 = var * count + bv * bc + bm_rel * bm_rel * count * bc / tot;
     const double nmean = mean + bm_rel * bc / tot, nvar = m2 / tot;
     g.stats[im] = nmean; g.stats[iv] = nvar;
-    if (tid < D) {
-      g.norm[tid] = (float)nmean;
-      g.norm[D + tid] = (float)(1.0 / sqrt(nvar + (double)g.epsilon));
+    if (c < D) {
+      g.norm[c] = (float)nmean;
+      g.norm[D + c] = (float)(1.0 / sqrt(nvar + (double)g.epsilon));
     } else {
       const float sc = (float)(1.0 / sqrt(nvar + (double)g.epsilon));
       g.norm[2 * D] = sc;
       if (g.rew_scale_out) *g.rew_scale_out = sc;
-      double sr = 0.0;
-      for (int w = 0; w < G; w++) sr += g.partial[((size_t)w * (D + 2) + D) * 2 + 2];
       g.stats[2 * D + 4] += sr;
     }
   }
@@ -308,30 +394,66 @@ __global__ void gae_kernel(const float *raw_rew, const float *scale, const float
 // ---------------------------------------------------------------- clip + Adam (TensorFlow's form), one workgroup
 __global__ __launch_bounds__(1024) void adam_kernel(float *theta, float *grad, float *m, float *v, int P, int *step, float lr,
                                                     float b1, float b2, float eps, float max_norm, float *norm_out) {
-  __shared__ double red[1024];
+  __shared__ double red[16];
+  __shared__ float lr_sh;
   const int tid = threadIdx.x;
+  constexpr int MAXV = 8;                      // float4s per thread: P <= 32768
+  const int n4 = P >> 2;
+  float4 gv[MAXV];
+  const float4 *g4 = reinterpret_cast<const float4 *>(grad);
   double s = 0.0;
-  for (int i = tid; i < P; i += 1024) { const double x = grad[i]; s += x * x; }
-  red[tid] = s;
-  __syncthreads();
-  for (int w = 512; w > 0; w >>= 1) {
-    if (tid < w) red[tid] += red[tid + w];
-    __syncthreads();
+#pragma unroll
+  for (int u = 0; u < MAXV; u++) {             // every load of the thread in flight together
+    const int i = tid + 1024 * u;
+    gv[u] = i < n4 ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  const float norm = (float)sqrt(red[0]);
+#pragma unroll
+  for (int u = 0; u < MAXV; u++)
+    s += (double)gv[u].x * gv[u].x + (double)gv[u].y * gv[u].y + (double)gv[u].z * gv[u].z + (double)gv[u].w * gv[u].w;
+  for (int i = (n4 << 2) + tid; i < P; i += 1024) s += (double)grad[i] * grad[i];
+  // wave sums by shuffles, then the 16 waves in order
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  if (tid == 0) {
+    const int t = *step + 1;
+    lr_sh = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
+  }
+  __syncthreads();
+  double tot = 0.0;
+#pragma unroll
+  for (int w = 0; w < 16; w++) tot += red[w];
+  const float norm = (float)sqrt(tot);
   const float scale = max_norm > 0.f ? max_norm / fmaxf(norm, max_norm) : 1.f;    // tf.clip_by_global_norm
-  const int t = *step + 1;
-  const double lr_t = (double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t));
-  for (int i = tid; i < P; i += 1024) {
-    const float gi = grad[i] * scale;
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-    m[i] = mi; v[i] = vi;
-    theta[i] -= (float)lr_t * mi / (sqrtf(vi) + eps);
-    grad[i] = 0.f;
+  const float lr_t = lr_sh;
+  float4 *t4 = reinterpret_cast<float4 *>(theta), *m4 = reinterpret_cast<float4 *>(m), *v4 = reinterpret_cast<float4 *>(v);
+  float4 *gw = reinterpret_cast<float4 *>(grad);
+  float4 tv[MAXV], mv[MAXV], vv[MAXV];
+#pragma unroll
+  for (int u = 0; u < MAXV; u++) {
+    const int i = tid + 1024 * u;
+    if (i < n4) { tv[u] = t4[i]; mv[u] = m4[i]; vv[u] = v4[i]; }
   }
-  __syncthreads();
-  if (tid == 0) { *step = t; if (norm_out) *norm_out = norm; }
+  auto upd = [&](float g, float &mi, float &vi, float &th) {
+    const float gi = g * scale;
+    mi = b1 * mi + (1.f - b1) * gi;
+    vi = b2 * vi + (1.f - b2) * gi * gi;
+    th -= lr_t * mi / (sqrtf(vi) + eps);
+  };
+#pragma unroll
+  for (int u = 0; u < MAXV; u++) {
+    const int i = tid + 1024 * u;
+    if (i < n4) {
+      upd(gv[u].x, mv[u].x, vv[u].x, tv[u].x); upd(gv[u].y, mv[u].y, vv[u].y, tv[u].y);
+      upd(gv[u].z, mv[u].z, vv[u].z, tv[u].z); upd(gv[u].w, mv[u].w, vv[u].w, tv[u].w);
+      t4[i] = tv[u]; m4[i] = mv[u]; v4[i] = vv[u]; gw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  for (int i = (n4 << 2) + tid; i < P; i += 1024) {
+    float mi = m[i], vi = v[i], th = theta[i];
+    upd(grad[i], mi, vi, th);
+    m[i] = mi; v[i] = vi; theta[i] = th; grad[i] = 0.f;
+  }
+  if (tid == 0) { *step = *step + 1; if (norm_out) *norm_out = norm; }
 }
 
 }  // namespace
@@ -470,7 +592,7 @@ int trex_policy_observe(TrexPolicy *p, const float *rows_dev, int row_stride, in
   BUF_TRY(rew_scale_out, sizeof(float), "trex_policy_observe: rew_scale_out");
   ObserveArgs a{rows_dev, p->stats, p->partial, p->norm, p->ret, raw_rew_out, done_out, rew_scale_out, p->counter,
                 p->n, row_stride, p->D, with_reward ? 1 : 0, gamma, p->epsilon};
-  hipLaunchKernelGGL(observe_kernel, dim3(p->G), dim3(128), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(observe_kernel, dim3(p->G), dim3(128 * OBS_GROUPS), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
   return TREX_OK;
 }
@@ -494,7 +616,8 @@ int trex_policy_act(TrexPolicy *p, const float *theta_dev, const float *rows_dev
   BUF_TRY(value_out, n * sizeof(float), "trex_policy_act: value_out");
   ActArgs a{theta_dev, rows_dev, p->norm, noise_dev, actions_dev, obs_out, act_out, logp_out, value_out,
             p->n, row_stride, value_only ? 1 : 0, clip_obs, p->lay};
-  hipLaunchKernelGGL(act_kernel, dim3((p->n + TILE - 1) / TILE), dim3(128), 0, (hipStream_t)stream, a);
+  const size_t lds_bytes = (((size_t)p->lay.count + 3) & ~(size_t)3) * sizeof(float) + (size_t)ACT_TILES * TILE * (MAXD + 1) * sizeof(float);
+  hipLaunchKernelGGL(act_kernel, dim3((p->n + ACT_TILES * TILE - 1) / (ACT_TILES * TILE)), dim3(256), lds_bytes, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
   return TREX_OK;
 }

@@ -58,10 +58,6 @@ class MlpPolicy(nn.Module):
     def mean(self, obs):
         return self._mlp("pi", obs)
 
-    @property
-    def logstd(self):
-        return self.p("logstd")
-
     def dist(self, obs):
         return torch.distributions.Normal(self.mean(obs), self.logstd.exp(), validate_args=False)   # the check syncs: not capturable
 
