@@ -83,6 +83,29 @@ int trex_policy_adam(TrexPolicy *policy, float *theta_dev, float *grad_dev, floa
                      float beta1, float beta2, float eps, float max_grad_norm, float *grad_norm_out, void *stream);
 int trex_policy_adam_reset(TrexPolicy *policy, void *stream);
 
+/* ---- the learner: one PPO2 minibatch step (ppo2's Model.train, trex_train.py:49-61) as two launches ----
+ * The rollout buffers are flat [num_samples, ...] f32 device arrays (num_samples = T x N): obs (NORMALISED, as the
+ * policy saw them), act, logp (log-probability under the rollout policy), val (its value estimates), adv, ret.
+ * perm_dev [>= first + mb] i64 device: a permutation of the sample indices (an epoch's shuffle); the minibatch is
+ * perm[first .. first + mb).
+ *
+ * trex_policy_minibatch_stats: for every minibatch k of an epoch (perm[k mb .. (k + 1) mb)) the mean of its
+ *   advantages and 1 / (std + 1e-8) (population std, as numpy's) -> stats_out [num_minibatches, 2] f32 device.
+ * trex_policy_minibatch_step: forward of both MLPs on the matrix cores, clipped surrogate (cliprange) + clipped value
+ *   loss (vf_coef) - ent_coef * entropy, analytic backward pass, global-norm clip (max_grad_norm), Adam in
+ *   TensorFlow's form (lr, beta1, beta2, eps) on theta / m / v [P]; the step count is the policy object's
+ *   (trex_policy_adam_reset). grad_dev [P]: receives the UNclipped gradient of this minibatch (scratch; tests read it).
+ *   adv_stats_dev [2]: this minibatch's row of the stats above. loss_sums_dev [2] f32 device, nullable: the
+ *   minibatch's mean surrogate loss and mean value loss are ADDED to it (zero it per update; divide by the steps). */
+int trex_policy_minibatch_stats(TrexPolicy *policy, const float *adv_dev, int64_t num_samples, const int64_t *perm_dev,
+                                int num_minibatches, int mb, float *stats_out_dev, void *stream);
+int trex_policy_minibatch_step(TrexPolicy *policy, float *theta_dev, float *grad_dev, float *m_dev, float *v_dev,
+                               const float *obs_dev, const float *act_dev, const float *logp_dev, const float *val_dev,
+                               const float *adv_dev, const float *ret_dev, int64_t num_samples, const int64_t *perm_dev,
+                               int first, int mb, const float *adv_stats_dev, float cliprange, float ent_coef, float vf_coef,
+                               float lr, float beta1, float beta2, float eps, float max_grad_norm, float *loss_sums_dev,
+                               void *stream);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

@@ -221,3 +221,76 @@ def test_trainer_rollout_and_one_minibatch_step_match_the_oracle():
     np.testing.assert_allclose(step, want - theta0, rtol=0, atol=0.02 * 3e-4)
     big = np.abs(gc["w"]) > 1e-3 * np.abs(gc["w"]).max()
     np.testing.assert_allclose(step[big], (want - theta0)[big], rtol=1e-3, atol=1e-5 * 3e-4)
+
+
+@pytest.mark.parametrize("mb", [1024, 1000])
+def test_native_minibatch_step_matches_the_oracle_and_autograd(mb):
+    """trex_policy_minibatch_step (forward + analytic backward on the matrix cores, partial sums, clip, Adam) on a
+    minibatch drawn through a permutation: the gradient against the f64 oracle's analytic gradient and against PyTorch
+    autograd on the same parameters, the losses, and the parameter update against the oracle's clip + TF-form Adam.
+    mb = 1000: the last tile of 32 samples is ragged."""
+    from trex_gym import _capi
+    from trex_gym.ppo import MlpPolicy
+    torch.manual_seed(5)
+    D, A, N = 75, 25, 6000
+    kern = _capi.Policy(64, D, A, 64, 0)
+    pol = MlpPolicy(kern.layout, kern.param_count, torch.device(DEV))
+    with torch.no_grad():
+        pol.theta.add_(0.05 * torch.randn_like(pol.theta))
+    obs = torch.randn(N, D, device=DEV).clamp(-10, 10)
+    with torch.no_grad():
+        d = pol.dist(obs)
+        act = d.loc + d.scale * torch.randn(N, A, device=DEV)
+        logp0 = d.log_prob(act).sum(-1) + 0.3 * torch.randn(N, device=DEV)      # an older policy: ratios leave the clip range
+        val0 = pol.value(obs) + 0.3 * torch.randn(N, device=DEV)
+    adv = 2 * torch.randn(N, device=DEV) + 0.5
+    ret = val0 + torch.randn(N, device=DEV)
+    perm = torch.randperm(N, device=DEV)
+    nmb = N // mb
+    stats = torch.zeros(nmb, 2, device=DEV)
+    kern.minibatch_stats(adv, perm, nmb, mb, stats)
+    for k in range(nmb):
+        a = adv[perm[k * mb:(k + 1) * mb]].double()
+        assert abs(stats[k, 0].item() - a.mean().item()) < 1e-6
+        assert abs(stats[k, 1].item() - 1.0 / (a.std(unbiased=False).item() + 1e-8)) < 1e-5 * stats[k, 1].item()
+    first = 2 * mb
+    idx = perm[first:first + mb]
+    mbt = [x.index_select(0, idx) for x in (obs, act, logp0, val0, adv, ret)]
+    h = [x.cpu().double().numpy() for x in mbt]
+    prm = _theta_to_params(kern, pol.theta)
+    theta0 = pol.theta.detach().cpu().double().numpy().copy()
+    out, grads = P.ppo_loss_and_grads(prm, h[0], h[1], -h[2], h[3], h[4], h[5], cliprange=0.2, ent_coef=0.01, vf_coef=0.5)
+    gflat = _grads_to_flat(kern, grads)
+    assert ((out["ratio"] > 1.2) | (out["ratio"] < 0.8)).mean() > 0.1
+    # autograd on the same parameters (f32)
+    a_n = (mbt[4] - mbt[4].mean()) / (mbt[4].std(unbiased=False) + 1e-8)
+    dd = pol.dist(mbt[0])
+    ratio = (dd.log_prob(mbt[1]).sum(-1) - mbt[2]).exp()
+    pg = torch.max(-a_n * ratio, -a_n * ratio.clamp(0.8, 1.2)).mean()
+    v = pol.value(mbt[0])
+    vclip = mbt[3] + (v - mbt[3]).clamp(-0.2, 0.2)
+    vf = 0.5 * torch.max((v - mbt[5]) ** 2, (vclip - mbt[5]) ** 2).mean()
+    (pg - 0.01 * dd.entropy().sum(-1).mean() + 0.5 * vf).backward()
+    g_auto = pol.grad.detach().clone()
+    pol.grad.zero_()
+    # the native step
+    m, vv, sums = torch.zeros_like(pol.theta), torch.zeros_like(pol.theta), torch.zeros(2, device=DEV)
+    gbuf = torch.zeros_like(pol.theta)
+    kern.minibatch_step(pol.theta, gbuf, m, vv, obs, act, logp0, val0, adv, ret, perm, first, mb, stats[2], cliprange=0.2,
+                        ent_coef=0.01, vf_coef=0.5, lr=3e-4, eps=1e-5, max_grad_norm=0.5, loss_sums=sums)
+    got = gbuf.cpu().double().numpy()
+    scale = np.abs(gflat).max()
+    np.testing.assert_allclose(got, gflat, rtol=1e-4, atol=1e-5 * scale)
+    np.testing.assert_allclose(got, g_auto.cpu().double().numpy(), rtol=1e-3, atol=1e-5 * scale)
+    assert abs(sums[0].item() - out["pg_loss"]) <= 1e-5 * max(1.0, abs(out["pg_loss"]))
+    assert abs(sums[1].item() - out["vf_loss"]) <= 1e-5 * max(1.0, abs(out["vf_loss"]))
+    gc, _ = P.clip_by_global_norm({"w": gflat}, 0.5)
+    want = P.Adam({"w": theta0}, lr=3e-4, epsilon=1e-5).step({"w": theta0}, gc)["w"]
+    step = pol.theta.detach().cpu().double().numpy() - theta0
+    np.testing.assert_allclose(step, want - theta0, rtol=0, atol=0.02 * 3e-4)
+    big = np.abs(gc["w"]) > 1e-3 * np.abs(gc["w"]).max()
+    np.testing.assert_allclose(step[big], (want - theta0)[big], rtol=1e-3, atol=1e-5 * 3e-4)
+    # a second step continues Adam's moments and step count (t = 2)
+    kern.minibatch_step(pol.theta, gbuf, m, vv, obs, act, logp0, val0, adv, ret, perm, first, mb, stats[2], cliprange=0.2,
+                        ent_coef=0.01, vf_coef=0.5, lr=3e-4, eps=1e-5, max_grad_norm=0.5, loss_sums=sums)
+    assert torch.isfinite(pol.theta).all() and float((pol.theta.cpu().double() - torch.tensor(want)).abs().max()) < 2.5 * 3e-4

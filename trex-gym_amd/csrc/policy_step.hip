@@ -30,45 +30,9 @@
 #include "../../include/trex_batch.h"
 #include "../../include/trex_policy.h"
 #include "internal.hpp"
+#include "policy_common.h"
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int HID = 64;        // hidden width (two 32-row MFMA tiles)
-constexpr int TILE = 32;       // envs per workgroup of act_kernel
-constexpr int MAXD = 128;      // LDS row of the observation tile (obs_dim + pad <= MAXD)
-constexpr int OBS_ROWS = 64;   // rows per workgroup of observe_kernel
-constexpr float LOG_2PI = 1.8378770664093453f;
-
-struct Layout {   // offsets into theta, trex_policy.h order
-  int D, A;
-  int pW1, pb1, pW2, pb2, pW3, pb3, vW1, vb1, vW2, vb2, vW3, vb3, logstd, count;
-};
-
-__host__ __device__ inline Layout make_layout(int D, int A) {
-  Layout l{};
-  l.D = D; l.A = A;
-  int o = 0;
-  l.pW1 = o; o += D * HID; l.pb1 = o; o += HID; l.pW2 = o; o += HID * HID; l.pb2 = o; o += HID; l.pW3 = o; o += HID * A; l.pb3 = o; o += A;
-  l.vW1 = o; o += D * HID; l.vb1 = o; o += HID; l.vW2 = o; o += HID * HID; l.vb2 = o; o += HID; l.vW3 = o; o += HID; l.vb3 = o; o += 1;
-  l.logstd = o; o += A;
-  l.count = o;
-  return l;
-}
-
-// tanh in ~10 instructions, |error| <= 2e-7 absolute (libm's tanhf expands to ~50 with branches; the policy step
-// evaluates 128 per lane): 1 - 2 / (exp(2|x|) + 1) away from 0, the odd series below |x| = 0.1 where that form cancels
-__device__ __forceinline__ float tanh_fast(float x) {
-  const float ax = fabsf(x), x2 = x * x;
-  const float e = __builtin_amdgcn_exp2f(ax * 2.885390081777927f);           // exp(2|x|); inf for large |x| -> t = 1
-  const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-  const float p = x * (1.0f + x2 * (-0.3333333333f + x2 * (0.1333333333f + x2 * (-0.05396825397f))));
-  return ax < 0.1f ? p : copysignf(t, x);
-}
-
-// row of accumulator register `reg` on a lane of half h = lane >> 5 (C/D layout of the 32x32 MFMA forms)
-__device__ __forceinline__ constexpr int rowmap(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
 // ---------------------------------------------------------------- act
 struct ActArgs {
@@ -459,29 +423,7 @@ __global__ __launch_bounds__(1024) void adam_kernel(float *theta, float *grad, f
 }  // namespace
 
 // ---------------------------------------------------------------- C-ABI
-struct TrexPolicy {
-  int n = 0, D = 0, A = 0, device = 0, G = 0;
-  Layout lay{};
-  double *stats = nullptr, *partial = nullptr;
-  float *norm = nullptr, *ret = nullptr;
-  unsigned *counter = nullptr;
-  int *adam_step = nullptr;
-  float epsilon = 1e-8f;        // VecNormalize's
-  std::vector<void *> allocs;
-  std::vector<TrexSeen> seen;
-};
-
 namespace {
-#define HIP_TRY(expr)                                                                          \
-  do {                                                                                         \
-    hipError_t _e = (expr);                                                                    \
-    if (_e != hipSuccess) return trex_fail(TREX_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
-  } while (0)
-#define BUF_TRY(ptr, bytes, what)                                                                       \
-  do {                                                                                                  \
-    if (int _c = trex_check_device_buffer(p->device, p->seen, (ptr), (size_t)(bytes), (what))) return _c; \
-  } while (0)
-
 int init_stats(TrexPolicy *p, hipStream_t s) {
   // RunningMeanStd(epsilon = 1e-4): mean 0, var 1, count 1e-4 (both)
   std::vector<double> st(2 * p->D + 5, 0.0);

@@ -1,0 +1,588 @@
+// PPO2 minibatch step as two launches (include/trex_policy.h: trex_policy_minibatch_step).
+//
+// What baselines' ppo2 Model.train does per minibatch through TensorFlow (trex_train.py:49-61: forward of both
+// MLPs, clipped surrogate + clipped value loss, backward, global-norm clip, Adam) costs a stock autograd framework ~90
+// small kernels (0.66 ms per 4096-sample minibatch even replayed from a HIP graph). Here:
+//
+//   learn_grad_kernel   one workgroup = one tile of 32 samples x 2 waves (policy net, value net). Forward exactly as
+//                       the rollout's act_kernel (transposed MFMA form, activations in registers). The backward pass
+//                       needs two kinds of contractions: over NEURONS (delta^T = W . delta_next^T: the B operand is
+//                       again the lane's own accumulator register, the A operand the LDS copy of W read transposed -
+//                       W2 is staged with a row stride of 65 words so that this read is conflict-free) and over
+//                       SAMPLES (grad W[k][j] = sum_env act[env][k] delta[env][j]: the sample index has to become
+//                       the MFMA's k dimension, so the activation tile and the delta tile make ONE trip through a
+//                       private LDS buffer of the wave, written [row][env] and read back with the env as k). Every
+//                       tile writes its gradient contribution to its own slice of a partial buffer: no atomics.
+//   learn_apply_kernel  sums the per-tile partials IN TILE ORDER (deterministic), adds the entropy term, and the last
+//                       workgroup to end takes the global norm (in workgroup order), clips and applies Adam in
+//                       TensorFlow's form to the flat parameter vector.
+//
+// The arithmetic is the one restated in f64 by oracle/ppo_oracle.py::ppo_loss_and_grads / clip_by_global_norm / Adam.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cmath>
+
+#include "../../include/trex_policy.h"
+#include "policy_common.h"
+
+namespace {
+
+constexpr int W2S = HID + 1;           // LDS row stride of W2 (transposed reads in the backward pass)
+constexpr int XS = MAXD + 1;           // LDS row stride of the observation tile
+constexpr int TS = TILE + 1;           // LDS row stride of the [row][env] transposition buffers
+
+struct LdsLayout {   // offsets (floats) of the LDS copy of theta, W2 padded to W2S. Block of net k starts at k * vf; inside a
+  //                    block: W1 at 0, then b1, W2, b2, W3, b3 (scalar fields only: an array indexed by the net would live in scratch)
+  int vf, b1, W2, b2, W3, logstd, X, buf, total;
+  __host__ __device__ int base(int net) const { return net ? vf : 0; }
+};
+__host__ __device__ inline LdsLayout make_lds_layout(int D, int A) {
+  LdsLayout l{};
+  l.b1 = D * HID; l.W2 = l.b1 + HID; l.b2 = l.W2 + HID * W2S; l.W3 = l.b2 + HID;
+  l.vf = l.W3 + HID * A + A;                       // the policy block: W3 [H, A], b3 [A]
+  int o = l.vf + l.W3 + HID + 1;                   // the value block: W3 [H, 1], b3 [1]
+  l.logstd = o; o += A;
+  o = (o + 3) & ~3;
+  l.X = o; o += TILE * XS;
+  l.buf = o; o += 2 * 2 * HID * TS;      // per wave: ACT [64][TS] + DEL [64][TS]
+  l.total = o;
+  return l;
+}
+
+struct LearnArgs {
+  const float *theta, *obs, *act, *logp0, *val0, *adv, *ret;
+  const long long *perm;
+  const float *adv_stats;      // [2]: mean and 1 / (std + 1e-8) of the minibatch's advantages
+  float *partial;              // [tiles][stride]
+  int first, mb, stride;
+  float cliprange, vf_coef;
+  Layout lay;
+};
+
+// sum over the 32 lanes of a half wave (same h), result on all of them: four DPP steps inside the 16-lane rows, then
+// gfx950's v_permlane16_swap (rows 0<->1, 2<->3)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float half_sum(float v) {
+  v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);   // row_half_mirror
+  v += dpp_f<0x140>(v);   // row_mirror
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ void copy_rows(float *dst, const float *src, int rows, int cols, int dst_stride, int tid, int nthreads) {
+  // [rows][cols] -> [rows][dst_stride], 8 loads in flight per thread and trip
+  const int n = rows * cols;
+  for (int i0 = tid; i0 < n; i0 += nthreads * 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const int i = i0 + nthreads * u; t[u] = src[i < n ? i : 0]; }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int i = i0 + nthreads * u;
+      if (i < n) { const int r = i / cols; dst[r * dst_stride + (i - r * cols)] = t[u]; }
+    }
+  }
+}
+
+__global__ __launch_bounds__(128) void learn_grad_kernel(LearnArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, net = tid >> 6;     // wave 0: policy net, wave 1: value net
+  const int D = g.lay.D, A = g.lay.A;
+  const LdsLayout L = make_lds_layout(D, A);
+  // ---- stage the parameters (W2 with padded rows) and the tile's observations
+  {
+    const float *th = g.theta;
+    float *P0 = lds, *P1 = lds + L.vf;
+    copy_rows(P0, th + g.lay.pW1, D, HID, HID, tid, 128);            copy_rows(P1, th + g.lay.vW1, D, HID, HID, tid, 128);
+    copy_rows(P0 + L.b1, th + g.lay.pb1, 1, HID, HID, tid, 128);     copy_rows(P1 + L.b1, th + g.lay.vb1, 1, HID, HID, tid, 128);
+    copy_rows(P0 + L.W2, th + g.lay.pW2, HID, HID, W2S, tid, 128);   copy_rows(P1 + L.W2, th + g.lay.vW2, HID, HID, W2S, tid, 128);
+    copy_rows(P0 + L.b2, th + g.lay.pb2, 1, HID, HID, tid, 128);     copy_rows(P1 + L.b2, th + g.lay.vb2, 1, HID, HID, tid, 128);
+    copy_rows(P0 + L.W3, th + g.lay.pW3, HID, A, A, tid, 128);       copy_rows(P1 + L.W3, th + g.lay.vW3, HID, 1, 1, tid, 128);
+    copy_rows(P0 + L.W3 + HID * A, th + g.lay.pb3, 1, A, A, tid, 128); copy_rows(P1 + L.W3 + HID, th + g.lay.vb3, 1, 1, 1, tid, 128);
+  }
+  copy_rows(lds + L.logstd, g.theta + g.lay.logstd, 1, A, A, tid, 128);
+  const int s0 = blockIdx.x * TILE;                       // first sample of the tile within the minibatch
+  float *X = lds + L.X;
+  constexpr int XC = 96;                                  // columns of X that the weight-gradient tiles read (3 x 32)
+  for (int idx0 = tid; idx0 < TILE * XC; idx0 += 128 * 4) {
+    float raw[4];
+    int ii[4], kk[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int idx = idx0 + 128 * u;
+      ii[u] = idx / XC; kk[u] = idx - ii[u] * XC;
+      const bool ok = idx < TILE * XC && kk[u] < D && s0 + ii[u] < g.mb;
+      const long long row = ok ? g.perm[g.first + s0 + ii[u]] : 0;
+      raw[u] = ok ? g.obs[(size_t)row * D + kk[u]] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (idx0 + 128 * u < TILE * XC) X[ii[u] * XS + kk[u]] = raw[u];
+  }
+  __syncthreads();
+  const int col = lane & 31, h = lane >> 5;
+  const bool valid = s0 + col < g.mb;
+  const long long sidx = valid ? g.perm[g.first + s0 + col] : 0;
+  const float *PB = lds + L.base(net);
+  const float *W1 = PB, *b1 = PB + L.b1, *W2 = PB + L.W2, *b2 = PB + L.b2;
+  const float *W3 = PB + L.W3, *b3 = PB + L.W3 + HID * (net ? 1 : A);
+  float *ACT = lds + L.buf + net * 2 * HID * TS, *DEL = ACT + HID * TS;
+  float *out = g.partial + (size_t)blockIdx.x * g.stride;
+  const float inv_mb = 1.0f / (float)g.mb;
+  const int Dp = (D + 1) & ~1;
+  // ================================================================ forward
+  f32x16 h1[2], h2[2];
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) h1[u][r] = b1[32 * u + rowmap(r, h)];
+  }
+#pragma unroll 4
+  for (int kk = 0; kk < Dp; kk += 2) {
+    const int k = kk + h;
+    const float b = X[col * XS + k];                  // (zero beyond D)
+    const int kc = k < D ? k : D - 1;
+#pragma unroll
+    for (int u = 0; u < 2; u++) h1[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(W1[kc * HID + 32 * u + col], b, h1[u], 0, 0, 0);
+  }
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) h1[u][r] = tanh_fast(h1[u][r]);
+  }
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) h2[u][r] = b2[32 * u + rowmap(r, h)];
+  }
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+      const int k = 32 * t + rowmap(s, h);
+#pragma unroll
+      for (int u = 0; u < 2; u++) h2[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(W2[k * W2S + 32 * u + col], h1[t][s], h2[u], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) h2[u][r] = tanh_fast(h2[u][r]);
+  }
+  // ================================================================ output layer, loss, output-layer gradients
+  f32x16 d2[2];      // dL / d(pre-activation of layer 2), transposed tile layout
+  if (net == 0) {
+    f32x16 mu;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { const int a = rowmap(r, h); mu[r] = a < A ? b3[a] : 0.f; }
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+#pragma unroll
+      for (int s = 0; s < 16; s++) {
+        const int k = 32 * t + rowmap(s, h);
+        mu = __builtin_amdgcn_mfma_f32_32x32x2f32(col < A ? W3[k * A + col] : 0.f, h2[t][s], mu, 0, 0, 0);
+      }
+    }
+    const float *ls = lds + L.logstd;
+    f32x16 z, isd;
+    float zz = 0.f, sum_ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int a = rowmap(r, h);
+      z[r] = 0.f; isd[r] = 0.f;
+      if (a < A) {
+        const float l = ls[a];
+        sum_ls += l;
+        isd[r] = expf(-l);
+        const float ac = valid ? g.act[(size_t)sidx * A + a] : mu[r];
+        z[r] = (ac - mu[r]) * isd[r];
+        zz = __builtin_fmaf(z[r], z[r], zz);
+      }
+    }
+    zz += __shfl_xor(zz, 32, 64);
+    sum_ls += __shfl_xor(sum_ls, 32, 64);
+    const float logp = -0.5f * zz - sum_ls - 0.5f * LOG_2PI * (float)A;
+    const float an = valid ? (g.adv[sidx] - g.adv_stats[0]) * g.adv_stats[1] : 0.f;
+    const float ratio = valid ? expf(logp - g.logp0[sidx]) : 1.f;
+    const float rc = fminf(fmaxf(ratio, 1.f - g.cliprange), 1.f + g.cliprange);
+    const float l1 = -an * ratio, l2 = -an * rc;
+    const bool through = l1 >= l2 || rc == ratio;      // the branch of max() that carries a gradient w.r.t. ratio
+    const float dlogp = valid && through ? -an * ratio * inv_mb : 0.f;     // dL/dlogp = dL/dratio * ratio
+    // dL/dmu = -dlogp ... careful with signs: L_pg = mean(max(-a r, -a clip(r))), r = exp(logp - logp0):
+    //   dL/dlogp = (-a) r / mb on the live branch; dlogp/dmu = z / sd; dlogp/dlogstd = z^2 - 1
+    f32x16 d3;
+    float pg = valid ? fmaxf(l1, l2) : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int a = rowmap(r, h);
+      d3[r] = dlogp * z[r] * isd[r];
+      const float gl = half_sum(a < A ? dlogp * (z[r] * z[r] - 1.f) : 0.f);      // d/dlogstd, summed over the tile's samples
+      const float gb = half_sum(d3[r]);
+      if (col == 0 && a < A) { out[g.lay.logstd + a] = gl; out[g.lay.pb3 + a] = gb; }
+    }
+    pg = half_sum(h == 0 ? pg : 0.f);
+    if (lane == 0) out[g.stride - 4] = pg;              // sum of the tile's surrogate terms (the mean is taken later)
+    // ---- grad W3[n2][a] = sum_env h2[env][n2] d3[env][a]: both tiles through the wave's LDS buffer, env becomes k
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) ACT[(32 * u + rowmap(r, h)) * TS + col] = h2[u][r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) DEL[rowmap(r, h) * TS + col] = d3[r];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 16; s++) {
+        const int env = 2 * s + h;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ACT[(32 * u + col) * TS + env], DEL[col * TS + env], acc, 0, 0, 0);
+      }
+      if (col < A) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) out[g.lay.pW3 + (32 * u + rowmap(r, h)) * A + col] = acc[r];
+      }
+    }
+    // ---- delta of layer 2: d2^T = (W3 d3^T) * (1 - h2^2); k = action = rowmap(s, h): B is the lane's own register
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 16; s++) {
+        const int a = rowmap(s, h);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a < A ? W3[(32 * u + col) * A + a] : 0.f, d3[s], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) d2[u][r] = acc[r] * (1.f - h2[u][r] * h2[u][r]);
+    }
+  } else {
+    // ---- value head: v = w . h2 + b; clipped value loss; its gradients are rank-1 in the sample
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+#pragma unroll
+      for (int s = 0; s < 16; s++) v = __builtin_fmaf(h2[t][s], W3[32 * t + rowmap(s, h)], v);
+    }
+    v += __shfl_xor(v, 32, 64);
+    v += b3[0];
+    const float v0 = valid ? g.val0[sidx] : v, rt = valid ? g.ret[sidx] : v;
+    const float dvc = fminf(fmaxf(v - v0, -g.cliprange), g.cliprange);
+    const float vclip = v0 + dvc;
+    const float e1 = (v - rt) * (v - rt), e2 = (vclip - rt) * (vclip - rt);
+    // 0.5 mean(max(e1, e2)): gradient (v - R) on the unclipped branch, (vclip - R) [clip inactive] on the other
+    float dv = e1 >= e2 ? (v - rt) : ((dvc == v - v0) ? (vclip - rt) : 0.f);
+    dv = valid ? g.vf_coef * dv * inv_mb : 0.f;
+    const float vl = half_sum((valid && h == 0) ? 0.5f * fmaxf(e1, e2) : 0.f);
+    const float gb = half_sum(h == 0 ? dv : 0.f);
+    if (lane == 0) { out[g.stride - 3] = vl; out[g.lay.vb3] = gb; }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int k = 32 * u + rowmap(r, h);
+        const float gw = half_sum(h2[u][r] * dv);            // grad W3[k] = sum_env h2[env][k] dv[env]
+        if (col == 0) out[g.lay.vW3 + k] = gw;
+        d2[u][r] = W3[k] * dv * (1.f - h2[u][r] * h2[u][r]);
+      }
+    }
+  }
+  // ================================================================ layers 2 and 1, the same for both nets
+  const int oW2 = net ? g.lay.vW2 : g.lay.pW2, ob2 = net ? g.lay.vb2 : g.lay.pb2;
+  const int oW1 = net ? g.lay.vW1 : g.lay.pW1, ob1 = net ? g.lay.vb1 : g.lay.pb1;
+  // ---- grad b2, grad W2[n1][n2] = sum_env h1[env][n1] d2[env][n2]
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float gb = half_sum(d2[u][r]);
+      if (col == 0) out[ob2 + 32 * u + rowmap(r, h)] = gb;
+      ACT[(32 * u + rowmap(r, h)) * TS + col] = h1[u][r];
+      DEL[(32 * u + rowmap(r, h)) * TS + col] = d2[u][r];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+#pragma unroll
+    for (int v = 0; v < 2; v++) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 16; s++) {
+        const int env = 2 * s + h;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ACT[(32 * u + col) * TS + env], DEL[(32 * v + col) * TS + env], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) out[oW2 + (32 * u + rowmap(r, h)) * HID + 32 * v + col] = acc[r];
+    }
+  }
+  // ---- delta of layer 1: d1^T = (W2 d2^T) * (1 - h1^2); W2 read transposed (row stride 65: conflict-free)
+  f32x16 d1[2];
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+#pragma unroll
+      for (int s = 0; s < 16; s++)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W2[(32 * u + col) * W2S + 32 * t + rowmap(s, h)], d2[t][s], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) d1[u][r] = acc[r] * (1.f - h1[u][r] * h1[u][r]);
+  }
+  // ---- grad b1, grad W1[k][n1] = sum_env x[env][k] d1[env][n1]
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float gb = half_sum(d1[u][r]);
+      if (col == 0) out[ob1 + 32 * u + rowmap(r, h)] = gb;
+      DEL[(32 * u + rowmap(r, h)) * TS + col] = d1[u][r];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+#pragma unroll
+    for (int v = 0; v < 2; v++) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 16; s++) {
+        const int env = 2 * s + h;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(X[env * XS + 32 * q + col], DEL[(32 * v + col) * TS + env], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int k = 32 * q + rowmap(r, h);
+        if (k < D) out[oW1 + k * HID + 32 * v + col] = acc[r];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- advantage statistics of every minibatch of an epoch
+__global__ __launch_bounds__(1024) void adv_stats_kernel(const float *adv, const long long *perm, int mb, float *out) {
+  __shared__ double red[16];
+  __shared__ double mean_sh;
+  const int tid = threadIdx.x;
+  const long long *p = perm + (size_t)blockIdx.x * mb;
+  double s = 0.0;
+  for (int i = tid; i < mb; i += 1024) s += (double)adv[p[i]];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) { double t = 0.0; for (int w = 0; w < 16; w++) t += red[w]; mean_sh = t / mb; }
+  __syncthreads();
+  const double mean = mean_sh;
+  s = 0.0;
+  for (int i = tid; i < mb; i += 1024) { const double d = (double)adv[p[i]] - mean; s += d * d; }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; w++) t += red[w];
+    out[2 * blockIdx.x] = (float)mean;
+    out[2 * blockIdx.x + 1] = (float)(1.0 / (sqrt(t / mb) + 1e-8));       // numpy's std: population
+  }
+}
+
+// ---------------------------------------------------------------- partial sums -> gradient -> clip -> Adam
+struct ApplyArgs {
+  const float *partial;
+  float *theta, *grad, *m, *v, *losses;     // losses [2]: running sums of the surrogate / value loss MEANS per minibatch
+  double *red;                              // [workgroups] partial squared norms
+  unsigned *counter;
+  int *step;
+  int tiles, stride, count, logstd_off, A;
+  float ent_coef, lr, b1, b2, eps, max_norm, inv_mb;
+};
+
+constexpr int AP_COLS = 64, AP_GROUPS = 4;
+__global__ __launch_bounds__(AP_COLS * AP_GROUPS) void learn_apply_kernel(ApplyArgs g) {
+  __shared__ float4 part[AP_GROUPS][AP_COLS];
+  __shared__ double wred[AP_COLS * AP_GROUPS / 64];
+  __shared__ bool last;
+  __shared__ float lr_sh, scale_sh;
+  const int tid = threadIdx.x, c = tid & (AP_COLS - 1), grp = tid / AP_COLS;
+  const int n4 = g.stride >> 2;                         // float4 columns of a partial row (the last one: the loss sums)
+  const int c4 = blockIdx.x * AP_COLS + c;
+  // ---- group q sums the tiles q, q + 4, ... in order (8 loads in flight), then group 0 adds the four in order
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c4 < n4) {
+    const float4 *P = reinterpret_cast<const float4 *>(g.partial) + c4;
+    for (int t0 = grp; t0 < g.tiles; t0 += 8 * AP_GROUPS) {
+      float4 x[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int t = t0 + u * AP_GROUPS; x[u] = t < g.tiles ? P[(size_t)t * n4] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+      for (int u = 0; u < 8; u++) { s.x += x[u].x; s.y += x[u].y; s.z += x[u].z; s.w += x[u].w; }
+    }
+  }
+  part[grp][c] = s;
+  __syncthreads();
+  double sq = 0.0;
+  if (grp == 0 && c4 < n4) {
+    float4 t = part[0][c];
+#pragma unroll
+    for (int q = 1; q < AP_GROUPS; q++) { t.x += part[q][c].x; t.y += part[q][c].y; t.z += part[q][c].z; t.w += part[q][c].w; }
+    if (c4 == n4 - 1) {                                 // the loss sums of the minibatch (x: surrogate, y: value)
+      if (g.losses) { g.losses[0] += t.x * g.inv_mb; g.losses[1] += t.y * g.inv_mb; }
+    } else {
+      float e[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int i = 4 * c4 + k;
+        if (i >= g.count) e[k] = 0.f;
+        else if (i >= g.logstd_off && i < g.logstd_off + g.A) e[k] -= g.ent_coef;      // d(-ent_coef * entropy)/dlogstd
+        sq += (double)e[k] * e[k];
+        if (i < g.count) g.grad[i] = e[k];
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  if ((tid & 63) == 0) wred[tid >> 6] = sq;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int w = 0; w < AP_COLS * AP_GROUPS / 64; w++) t += wred[w];
+    g.red[blockIdx.x] = t;
+  }
+  // ---- the last workgroup to end: global norm (workgroup order), clip, Adam on the whole vector
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) last = atomicAdd(g.counter, 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (tid == 0) {
+    double t = 0.0;
+    for (unsigned w = 0; w < gridDim.x; w++) t += g.red[w];
+    const float norm = (float)sqrt(t);
+    scale_sh = g.max_norm > 0.f ? g.max_norm / fmaxf(norm, g.max_norm) : 1.f;        // tf.clip_by_global_norm
+    const int st = *g.step + 1;
+    lr_sh = (float)((double)g.lr * sqrt(1.0 - pow((double)g.b2, (double)st)) / (1.0 - pow((double)g.b1, (double)st)));
+    *g.step = st;
+    *g.counter = 0u;
+  }
+  __syncthreads();
+  const float scale = scale_sh, lr_t = lr_sh;
+  const int P4 = g.count >> 2;
+  float4 *t4 = reinterpret_cast<float4 *>(g.theta), *m4 = reinterpret_cast<float4 *>(g.m), *v4 = reinterpret_cast<float4 *>(g.v);
+  const float4 *g4 = reinterpret_cast<const float4 *>(g.grad);
+  auto upd = [&](float gr, float &mi, float &vi, float &th) {
+    const float gi = gr * scale;
+    mi = g.b1 * mi + (1.f - g.b1) * gi;
+    vi = g.b2 * vi + (1.f - g.b2) * gi * gi;
+    th -= lr_t * mi / (sqrtf(vi) + g.eps);
+  };
+  for (int i0 = tid; i0 < P4; i0 += 256 * 4) {
+    float4 gv[4], tv[4], mv[4], vv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = i0 + 256 * u;
+      if (i < P4) { gv[u] = g4[i]; tv[u] = t4[i]; mv[u] = m4[i]; vv[u] = v4[i]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = i0 + 256 * u;
+      if (i < P4) {
+        upd(gv[u].x, mv[u].x, vv[u].x, tv[u].x); upd(gv[u].y, mv[u].y, vv[u].y, tv[u].y);
+        upd(gv[u].z, mv[u].z, vv[u].z, tv[u].z); upd(gv[u].w, mv[u].w, vv[u].w, tv[u].w);
+        t4[i] = tv[u]; m4[i] = mv[u]; v4[i] = vv[u];
+      }
+    }
+  }
+  for (int i = (P4 << 2) + tid; i < g.count; i += 256) {
+    float mi = g.m[i], vi = g.v[i], th = g.theta[i];
+    upd(g.grad[i], mi, vi, th);
+    g.m[i] = mi; g.v[i] = vi; g.theta[i] = th;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int trex_policy_minibatch_stats(TrexPolicy *p, const float *adv_dev, int64_t num_samples, const int64_t *perm_dev, int num_minibatches,
+                                int mb, float *stats_out_dev, void *stream) {
+  if (!p || !adv_dev || !perm_dev || !stats_out_dev || num_minibatches <= 0 || mb <= 0 || num_samples <= 0)
+    return trex_fail(TREX_E_INVALID, "trex_policy_minibatch_stats: bad argument");
+  TrexDeviceGuard guard(p->device);
+  BUF_TRY(perm_dev, (size_t)num_minibatches * mb * sizeof(int64_t), "trex_policy_minibatch_stats: perm");
+  BUF_TRY(stats_out_dev, (size_t)num_minibatches * 2 * sizeof(float), "trex_policy_minibatch_stats: stats_out");
+  BUF_TRY(adv_dev, (size_t)num_samples * sizeof(float), "trex_policy_minibatch_stats: adv");
+  hipLaunchKernelGGL(adv_stats_kernel, dim3(num_minibatches), dim3(1024), 0, (hipStream_t)stream, adv_dev,
+                     reinterpret_cast<const long long *>(perm_dev), mb, stats_out_dev);
+  HIP_TRY(hipGetLastError());
+  return TREX_OK;
+}
+
+int trex_policy_minibatch_step(TrexPolicy *p, float *theta_dev, float *grad_dev, float *m_dev, float *v_dev, const float *obs_dev,
+                               const float *act_dev, const float *logp_dev, const float *val_dev, const float *adv_dev,
+                               const float *ret_dev, int64_t num_samples, const int64_t *perm_dev, int first, int mb,
+                               const float *adv_stats_dev, float cliprange, float ent_coef, float vf_coef, float lr, float beta1,
+                               float beta2, float eps, float max_grad_norm, float *loss_sums_dev, void *stream) {
+  if (!p || !theta_dev || !grad_dev || !m_dev || !v_dev || !obs_dev || !act_dev || !logp_dev || !val_dev || !adv_dev || !ret_dev ||
+      !perm_dev || !adv_stats_dev)
+    return trex_fail(TREX_E_INVALID, "trex_policy_minibatch_step: null argument");
+  if (mb <= 0 || first < 0 || num_samples <= 0) return trex_fail(TREX_E_INVALID, "trex_policy_minibatch_step: bad sizes");
+  TrexDeviceGuard guard(p->device);
+  const size_t P = (size_t)p->lay.count, N = (size_t)num_samples;
+  BUF_TRY(theta_dev, P * sizeof(float), "trex_policy_minibatch_step: theta");
+  BUF_TRY(grad_dev, P * sizeof(float), "trex_policy_minibatch_step: grad");
+  BUF_TRY(m_dev, P * sizeof(float), "trex_policy_minibatch_step: m");
+  BUF_TRY(v_dev, P * sizeof(float), "trex_policy_minibatch_step: v");
+  BUF_TRY(obs_dev, N * p->D * sizeof(float), "trex_policy_minibatch_step: obs");
+  BUF_TRY(act_dev, N * p->A * sizeof(float), "trex_policy_minibatch_step: act");
+  BUF_TRY(logp_dev, N * sizeof(float), "trex_policy_minibatch_step: logp");
+  BUF_TRY(val_dev, N * sizeof(float), "trex_policy_minibatch_step: val");
+  BUF_TRY(adv_dev, N * sizeof(float), "trex_policy_minibatch_step: adv");
+  BUF_TRY(ret_dev, N * sizeof(float), "trex_policy_minibatch_step: ret");
+  BUF_TRY(perm_dev, ((size_t)first + mb) * sizeof(int64_t), "trex_policy_minibatch_step: perm");
+  BUF_TRY(adv_stats_dev, 2 * sizeof(float), "trex_policy_minibatch_step: adv_stats");
+  BUF_TRY(loss_sums_dev, 2 * sizeof(float), "trex_policy_minibatch_step: loss_sums");
+  const int tiles = (mb + TILE - 1) / TILE;
+  const int stride = (int)(((P + 3) & ~(size_t)3) + 4);       // parameters, padded to float4, + one float4 of loss sums
+  const int apply_groups = ((stride >> 2) + AP_COLS - 1) / AP_COLS;
+  if (tiles > p->grad_tiles) {      // workspace, grown on demand (never inside a graph capture: the first call is eager)
+    float *buf = nullptr;
+    HIP_TRY(hipMalloc((void **)&buf, (size_t)tiles * stride * sizeof(float)));
+    p->allocs.push_back(buf);
+    p->grad_partial = buf; p->grad_tiles = tiles;
+    if (!p->learn_counter) {
+      HIP_TRY(hipMalloc((void **)&p->learn_counter, sizeof(unsigned)));
+      p->allocs.push_back(p->learn_counter);
+      HIP_TRY(hipMemset(p->learn_counter, 0, sizeof(unsigned)));
+      HIP_TRY(hipMalloc((void **)&p->learn_red, 4096 * sizeof(double)));
+      p->allocs.push_back(p->learn_red);
+    }
+  }
+  const LdsLayout L = make_lds_layout(p->D, p->A);
+  LearnArgs a{theta_dev, obs_dev, act_dev, logp_dev, val_dev, adv_dev, ret_dev, reinterpret_cast<const long long *>(perm_dev),
+              adv_stats_dev, p->grad_partial, first, mb, stride, cliprange, vf_coef, p->lay};
+  hipLaunchKernelGGL(learn_grad_kernel, dim3(tiles), dim3(128), (size_t)L.total * sizeof(float), (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
+  ApplyArgs b{p->grad_partial, theta_dev, grad_dev, m_dev, v_dev, loss_sums_dev, p->learn_red, p->learn_counter, p->adam_step,
+              tiles, stride, p->lay.count, p->lay.logstd, p->A, ent_coef, lr, beta1, beta2, eps, max_grad_norm, 1.0f / (float)mb};
+  hipLaunchKernelGGL(learn_apply_kernel, dim3(apply_groups), dim3(AP_COLS * AP_GROUPS), 0, (hipStream_t)stream, b);
+  HIP_TRY(hipGetLastError());
+  return TREX_OK;
+}
+
+}  // extern "C"

@@ -68,8 +68,11 @@ class MlpPolicy(nn.Module):
 class PPO:
     def __init__(self, env, nsteps=32, nminibatches=32, noptepochs=4, gamma=0.99, lam=0.95, lr=3e-4,
                  cliprange=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, clip_obs=10.0, clip_rew=10.0,
-                 seed=0, use_graphs=False):
-        """use_graphs: capture the whole nsteps rollout (policy kernel + env step + statistics kernel per step) and
+                 seed=0, use_graphs=False, native_learner=True):
+        """native_learner: the minibatch step is two HIP launches (trex_policy_minibatch_step: forward + analytic
+        backward on the matrix cores, then partial sums -> clip -> Adam) instead of ~90 autograd kernels; False keeps
+        the PyTorch autograd path (the f32 reference the native step is tested against).
+        use_graphs: capture the whole nsteps rollout (policy kernel + env step + statistics kernel per step) and
         one epoch of minibatch updates as HIP graphs and replay them - everything launched is stream-ordered, so it
         is capture-safe (tests/test_gpu_invariants.py)."""
         self.env = env
@@ -84,8 +87,10 @@ class PPO:
         self.policy = MlpPolicy(self.kern.layout, self.kern.param_count, self.dev)
         self.adam_m = torch.zeros_like(self.policy.theta)
         self.adam_v = torch.zeros_like(self.policy.theta)
-        self.use_graphs = use_graphs
+        self.use_graphs, self.native_learner = use_graphs, native_learner
         self._rollout_graph = self._update_graph = None
+        self.mb_stats = torch.zeros(nminibatches, 2, device=self.dev)
+        self.loss_sums = torch.zeros(2, device=self.dev)
         self.total_env_steps = 0
         T = nsteps
         self.noise = torch.empty(T, n, ad, device=self.dev)
@@ -166,6 +171,17 @@ class PPO:
     def _epoch(self, srcs, N, mb):
         """One epoch: a fresh permutation, nminibatches optimiser steps; returns the summed (pg, vf, ent)."""
         perm = torch.rand(N, device=self.dev).argsort()     # (capturable: no host round trip, unlike randperm's size logic)
+        if self.native_learner:
+            obs, act, logp0, val0, adv, ret = srcs
+            k, pol = self.kern, self.policy
+            k.minibatch_stats(adv, perm, self.nminibatches, mb, self.mb_stats)
+            self.loss_sums.zero_()
+            for i in range(self.nminibatches):
+                k.minibatch_step(pol.theta, pol.grad, self.adam_m, self.adam_v, obs, act, logp0, val0, adv, ret, perm, i * mb, mb,
+                                 self.mb_stats[i], self.cliprange, self.ent_coef, self.vf_coef, self.lr, 0.9, 0.999, 1e-5,
+                                 self.max_grad_norm, self.loss_sums)
+            ent = (pol.logstd.detach() + 0.5 * (math.log(2 * math.pi) + 1.0)).sum() * self.nminibatches   # (of the updated policy)
+            return torch.cat([self.loss_sums, ent.reshape(1)])
         acc = torch.zeros(3, device=self.dev)
         for k in range(self.nminibatches):
             idx = perm[k * mb:(k + 1) * mb]
@@ -185,9 +201,12 @@ class PPO:
                 keep = self.policy.theta.clone()
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):      # warm-up outside the capture (library set-up, autograd buffers)
-                    for _ in range(3):
-                        self._minibatch_step(*[x[:mb] for x in srcs])
+                with torch.cuda.stream(side):      # warm-up outside the capture (library set-up, autograd buffers, workspace)
+                    if self.native_learner:
+                        self._epoch(srcs, N, mb)
+                    else:
+                        for _ in range(3):
+                            self._minibatch_step(*[x[:mb] for x in srcs])
                     torch.rand(N, device=self.dev).argsort()
                 torch.cuda.current_stream().wait_stream(side)
                 with torch.no_grad():              # undo the warm-up: same parameters and a fresh Adam state
