@@ -23,6 +23,8 @@ hipError_t trex_launch_pack_state(const TrexDeviceModel *, TrexBatchArrays, int,
 hipError_t trex_launch_head(const TrexDeviceModel *, TrexBatchArrays, int, float *, hipStream_t);
 hipError_t trex_launch_link_transforms(const TrexDeviceModel *, TrexBatchArrays, int, float *, hipStream_t, int);
 hipError_t trex_launch_fill(float *, float, int, hipStream_t);
+hipError_t trex_launch_scalars_get(TrexBatchArrays, int, int32_t *, float *, int32_t *, hipStream_t);
+hipError_t trex_launch_scalars_set(TrexBatchArrays, int, const int32_t *, int, int, hipStream_t);
 hipError_t trex_launch_fill_u8(uint8_t *, uint8_t, int, hipStream_t);
 hipError_t trex_launch_copy_mass_scale(const float *, float *, int, int, hipStream_t);
 int trex_step_lds_bytes(void);
@@ -400,12 +402,9 @@ int trex_batch_create(const TrexModel *model, int num_envs, int device, TrexBatc
   A(n * TREX_TL * sizeof(float), (void **)&b->arr.tau);
   A(n * TREX_TL * sizeof(float), (void **)&b->arr.mass_scale);
   A(n * sizeof(float), (void **)&b->arr.friction);
-  A(n, (void **)&b->arr.motors_on);
-  A(n * sizeof(int32_t), (void **)&b->arr.contact_count);
-  A(n * sizeof(float), (void **)&b->arr.normal_impulse);
   A(TREX_BAL_WORDS(n) * sizeof(int32_t), (void **)&b->arr.balance);
-  A(n * sizeof(int32_t), (void **)&b->arr.episode_steps);
   b->arr.max_episode_steps = 0;
+  b->arr.domain = 0;
   size_t nv = model->host.hull_xyz.size();
   A((nv ? nv : 1) * sizeof(float4), (void **)&b->arr.hull);
   const size_t nl = model->host.link_names.size();
@@ -565,10 +564,7 @@ int trex_batch_set_episode_limit(TrexBatch *b, int max_episode_steps, const int3
   DeviceGuard guard(b->device);
   BUF_TRY(episode_steps_dev, (size_t)b->n * sizeof(int32_t), "trex_batch_set_episode_limit: episode_steps");
   b->arr.max_episode_steps = max_episode_steps;
-  if (episode_steps_dev)
-    HIP_TRY(hipMemcpyAsync(b->arr.episode_steps, episode_steps_dev, (size_t)b->n * sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
-  else
-    HIP_TRY(hipMemsetAsync(b->arr.episode_steps, 0, (size_t)b->n * sizeof(int32_t), (hipStream_t)stream));
+  HIP_TRY(trex_launch_scalars_set(b->arr, b->n, episode_steps_dev, 1, -1, (hipStream_t)stream));
   return TREX_OK;
 }
 int trex_batch_get_episode_steps(TrexBatch *b, int32_t *episode_steps_dev, void *stream) {
@@ -576,7 +572,7 @@ int trex_batch_get_episode_steps(TrexBatch *b, int32_t *episode_steps_dev, void 
   if (!episode_steps_dev) return fail(TREX_E_INVALID, "episode_steps is null");
   DeviceGuard guard(b->device);
   BUF_TRY(episode_steps_dev, (size_t)b->n * sizeof(int32_t), "trex_batch_get_episode_steps: episode_steps");
-  HIP_TRY(hipMemcpyAsync(episode_steps_dev, b->arr.episode_steps, (size_t)b->n * sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  HIP_TRY(trex_launch_scalars_get(b->arr, b->n, nullptr, nullptr, episode_steps_dev, (hipStream_t)stream));
   return TREX_OK;
 }
 
@@ -600,7 +596,7 @@ int trex_batch_set_state(TrexBatch *b, const float *state_dev, void *stream) {
 int trex_batch_set_motors_enabled(TrexBatch *b, int enabled, void *stream) {
   if (check_batch(b)) return TREX_E_INVALID;
   DeviceGuard guard(b->device);
-  HIP_TRY(trex_launch_fill_u8(b->arr.motors_on, enabled ? 1 : 0, b->n, (hipStream_t)stream));
+  HIP_TRY(trex_launch_scalars_set(b->arr, b->n, nullptr, 0, enabled ? 1 : 0, (hipStream_t)stream));
   return TREX_OK;
 }
 
@@ -658,6 +654,7 @@ int trex_batch_set_domain(TrexBatch *b, const float *mass_scale_dev, const float
   BUF_TRY(friction_dev, (size_t)b->n * sizeof(float), "trex_batch_set_domain: friction");
   if (mass_scale_dev) HIP_TRY(trex_launch_copy_mass_scale(mass_scale_dev, b->arr.mass_scale, b->n, b->nb, (hipStream_t)stream));
   if (friction_dev) HIP_TRY(hipMemcpyAsync(b->arr.friction, friction_dev, b->n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (mass_scale_dev || friction_dev) b->arr.domain = 1;   // from now on the step launches read the per-env arrays
   return TREX_OK;
 }
 
@@ -666,8 +663,8 @@ int trex_batch_contact_stats(TrexBatch *b, int32_t *count_dev, float *normal_imp
   DeviceGuard guard(b->device);
   BUF_TRY(count_dev, (size_t)b->n * sizeof(int32_t), "trex_batch_contact_stats: count");
   BUF_TRY(normal_impulse_dev, (size_t)b->n * sizeof(float), "trex_batch_contact_stats: normal_impulse");
-  if (count_dev) HIP_TRY(hipMemcpyAsync(count_dev, b->arr.contact_count, b->n * sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
-  if (normal_impulse_dev) HIP_TRY(hipMemcpyAsync(normal_impulse_dev, b->arr.normal_impulse, b->n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (count_dev || normal_impulse_dev)
+    HIP_TRY(trex_launch_scalars_get(b->arr, b->n, count_dev, normal_impulse_dev, nullptr, (hipStream_t)stream));
   return TREX_OK;
 }
 

@@ -44,9 +44,17 @@ struct TrexDeviceModel {
 };
 
 /* Per-env state in HBM. One row per env, padded so that a 32-lane team reads whole 128-B segments:
- *   base  [N][16]  pos(3) quat xyzw(4) v(3) w(3) pad(3)
- *   q, qd, tau, mass_scale  [N][32]  indexed by BODY lane (lane 0 unused)
- *   friction [N], motors_on [N] (u8), contact stats [N] */
+ *   base  [N][16]  pos(3) quat xyzw(4) v(3) w(3) | [13] contact count of the last substep (bits 0..7) + motors-on flag
+ *                  (bit 8), as an int | [14] summed normal impulse of the last substep | [15] env-steps since the last
+ *                  reset, as an int (the harness's episode limit). ONE 64-byte line carries everything the step launch
+ *                  reads and writes per env besides the joint rows (round 2 kept the four scalars in arrays of their
+ *                  own: four more partial-line reads and writes per env-step).
+ *   q, qd, tau  [N][32]  indexed by BODY lane (lane 0 unused)
+ *   mass_scale [N][32], friction [N]: domain randomisation; read only when `domain` is set (trex_batch_set_domain) */
+#define TREX_BASE_FLAGS 13
+#define TREX_BASE_IMPULSE 14
+#define TREX_BASE_STEPS 15
+#define TREX_MOTORS_BIT 256
 #define TREX_BAL_PHASE 0
 #define TREX_BAL_FINISHED 1
 #define TREX_BAL_COUNTS 16
@@ -56,14 +64,12 @@ struct TrexDeviceModel {
 
 struct TrexBatchArrays {
   float *base, *q, *qd, *tau, *mass_scale, *friction;
-  uint8_t *motors_on;
-  int32_t *contact_count;
-  float *normal_impulse;
+  int32_t domain;         /* != 0: per-env mass_scale / friction are in force (else the model's values: no loads) */
+  int32_t pad0_;
   int32_t *balance;       /* wave balance, device-side state only: [TREX_BAL_PHASE] which of the two list sets the next
                              step launch reads, [TREX_BAL_FINISHED] waves of the running launch that have ended,
                              [TREX_BAL_COUNTS + 16 p + c] envs filed under contact count c in set p,
                              [TREX_BAL_LISTS + (16 p + c) N + i] the i-th of them */
-  int32_t *episode_steps; /* [N] env-steps since the env's last reset (the harness's episode limit) */
   int32_t max_episode_steps;  /* 0 = no limit; > 0: an env whose count reaches it is reset INSIDE the step launch */
   int32_t pad_;
   float4 *hull;  /* [nv] body-frame collision points: xyz + support radius (0 for hull vertices) */

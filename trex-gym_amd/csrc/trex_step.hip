@@ -423,8 +423,9 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
   // ---- per-env state: the base pose and twist are wave-uniform (SGPRs); q / qd / motor torque / target of
   // body lane b are parked in LDS (W.st) and read where a phase needs them
   float pos[3], quat[4], bv[3], bw[3];
-  const float mu = uni(args.arr.friction[env]);
+  const float mu = args.arr.domain ? uni(args.arr.friction[env]) : M->prm[TP_FRICTION];
   bool motors_on;
+  int flags_in = 0, steps_in = 0;      // base row words 13 and 15 (device_model.h)
   bool do_reset = false;
   bool bad;
   if (RESET) do_reset = args.reset_mask ? (args.reset_mask[env] != 0) : true;
@@ -456,13 +457,16 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
       for (int c = 0; c < 3; c++) { pos[c] = uni(b[c]); bv[c] = uni(b[7 + c]); bw[c] = uni(b[10 + c]); }
 #pragma unroll
       for (int c = 0; c < 4; c++) quat[c] = uni(b[3 + c]);
+      flags_in = uni(__float_as_int(b[TREX_BASE_FLAGS]));
       if (tid < TL) {
         q = args.arr.q[(size_t)env * TL + tid];
         qd = args.arr.qd[(size_t)env * TL + tid];
-        mtau = args.arr.tau[(size_t)env * TL + tid];
+        // (the stored motor torque is only handed out again by a reset launch that leaves the env alone; a step
+        // overwrites it in its first substep: no load)
       }
-      motors_on = RESET ? (args.arr.motors_on[env] != 0) : true;
+      motors_on = RESET ? ((flags_in & TREX_MOTORS_BIT) != 0) : true;
     }
+    steps_in = uni(__float_as_int(args.arr.base[(size_t)env * 16 + TREX_BASE_STEPS]));
     // non-finite input state (checked here as well as after the step: fminf/fmaxf clamps launder NaNs)
     bool badl = !(fabsf(q) < 3.0e38f) || !(fabsf(qd) < 3.0e38f);
 #pragma unroll
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
   int age = 0;
   bool time_up = false;
   if (!RESET && args.arr.max_episode_steps > 0) {
-    age = args.arr.episode_steps[env] + 1;
+    age = steps_in + 1;
     time_up = age >= args.arr.max_episode_steps;
   }
   const int n_total = n_sub + ((!RESET && time_up) ? 1 : 0);
@@ -1029,7 +1033,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
       }
       const TrexDeviceModel *Mi = Mo();
       float comb[3], inb[6];
-      const float mscale = args.arr.mass_scale[(size_t)env * TL + bl];
+      const float mscale = args.arr.domain ? args.arr.mass_scale[(size_t)env * TL + bl] : 1.0f;
       const float mass = Mi->mass[bl] * mscale;
 #pragma unroll
       for (int c = 0; c < 3; c++) comb[c] = Mi->com[c][bl];
@@ -1900,21 +1904,18 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
     // base row: pos(3) quat(4) v(3) w(3); lane k < 13 stores word k (static selects: a dynamically indexed
     // register array would be demoted to scratch memory)
     float *b = args.arr.base + (size_t)env * 16;
-    const float row[13] = {pos[0], pos[1], pos[2], quat[0], quat[1], quat[2], quat[3], bv[0], bv[1], bv[2], bw[0], bw[1], bw[2]};
+    // ... + contact count | motors flag, summed normal impulse, episode steps: the whole 64-byte line in one store
+    const int steps_out = (RESET || args.arr.max_episode_steps > 0) ? ((RESET || time_up || env_bad) ? 0 : age) : steps_in;
+    const float row[16] = {pos[0], pos[1], pos[2], quat[0], quat[1], quat[2], quat[3], bv[0], bv[1], bv[2], bw[0], bw[1], bw[2],
+                           __int_as_float((stat_nc & 255) | (motors_on ? TREX_MOTORS_BIT : 0)), stat_imp, __int_as_float(steps_out)};
     float word = row[0];
 #pragma unroll
-    for (int k = 1; k < 13; k++) word = (lt == k) ? row[k] : word;
-    if (lt < 13) b[lt] = word;
+    for (int k = 1; k < 16; k++) word = (lt == k) ? row[k] : word;
+    if (lt < 16) b[lt] = word;
     if (lt < TL) {
       args.arr.q[(size_t)env * TL + lt] = q;
       args.arr.qd[(size_t)env * TL + lt] = qd;
       args.arr.tau[(size_t)env * TL + lt] = mtau;
-    }
-    if (lt == 0) {
-      args.arr.motors_on[env] = motors_on ? 1 : 0;
-      args.arr.contact_count[env] = stat_nc;
-      args.arr.normal_impulse[env] = stat_imp;
-      if (RESET || args.arr.max_episode_steps > 0) args.arr.episode_steps[env] = (RESET || time_up || env_bad) ? 0 : age;
     }
   }
   if (args.obs && is_joint) {
@@ -2080,6 +2081,27 @@ __global__ __launch_bounds__(64) void trex_link_transforms_kernel(KernelArgs arg
   }
 }
 
+// the per-env scalars of the base row (device_model.h): read out / set by the C-ABI's accessors
+__global__ void trex_scalars_get_kernel(const float *base, int n, int32_t *count, float *impulse, int32_t *steps) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const float *b = base + (size_t)e * 16;
+  if (count) count[e] = __float_as_int(b[TREX_BASE_FLAGS]) & 255;
+  if (impulse) impulse[e] = b[TREX_BASE_IMPULSE];
+  if (steps) steps[e] = __float_as_int(b[TREX_BASE_STEPS]);
+}
+__global__ void trex_scalars_set_kernel(float *base, int n, const int32_t *steps, int set_steps, int motors) {
+  // set_steps: word 15 <- steps[e] (or 0 if steps == null); motors >= 0: the motors flag <- motors
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  float *b = base + (size_t)e * 16;
+  if (set_steps) b[TREX_BASE_STEPS] = __int_as_float(steps ? steps[e] : 0);
+  if (motors >= 0) {
+    const int f = __float_as_int(b[TREX_BASE_FLAGS]);
+    b[TREX_BASE_FLAGS] = __int_as_float(motors ? (f | TREX_MOTORS_BIT) : (f & ~TREX_MOTORS_BIT));
+  }
+}
+
 __global__ void trex_fill_kernel(float *p, float v, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -2141,6 +2163,15 @@ hipError_t trex_launch_link_transforms(const TrexDeviceModel *model, TrexBatchAr
   KernelArgs a{model, arr, n, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, nullptr};
   if (visuals) hipLaunchKernelGGL(trex_link_transforms_kernel, dim3(n), dim3(64), 0, stream, a, out, arr.num_visuals, arr.visual_body, arr.visual_tf);
   else hipLaunchKernelGGL(trex_link_transforms_kernel, dim3(n), dim3(64), 0, stream, a, out, arr.num_links, arr.link_body, arr.link_tf);
+  return hipGetLastError();
+}
+
+hipError_t trex_launch_scalars_get(TrexBatchArrays arr, int n, int32_t *count, float *impulse, int32_t *steps, hipStream_t stream) {
+  hipLaunchKernelGGL(trex_scalars_get_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, arr.base, n, count, impulse, steps);
+  return hipGetLastError();
+}
+hipError_t trex_launch_scalars_set(TrexBatchArrays arr, int n, const int32_t *steps, int set_steps, int motors, hipStream_t stream) {
+  hipLaunchKernelGGL(trex_scalars_set_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, arr.base, n, steps, set_steps, motors);
   return hipGetLastError();
 }
 
