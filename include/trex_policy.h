@@ -22,7 +22,8 @@
  * Flat parameter vector `theta` (f32, trex_policy_param_count() elements), weights stored [in][out]:
  *   pi.W1 [D,H] pi.b1 [H] pi.W2 [H,H] pi.b2 [H] pi.W3 [H,A] pi.b3 [A]
  *   vf.W1 [D,H] vf.b1 [H] vf.W2 [H,H] vf.b2 [H] vf.W3 [H,1] vf.b3 [1]   logstd [A]
- * with D = obs_dim, A = act_dim, H = hidden = 64; trex_policy_param_offsets() returns the 13 offsets in this order.
+ * with D = obs_dim, A = act_dim, H = hidden = 64; every block starts on a multiple of 4 floats (a few unused pad
+ * elements follow the blocks whose size is not one); trex_policy_param_offsets() returns the 13 offsets in this order.
  */
 #ifndef TREX_POLICY_H
 #define TREX_POLICY_H

@@ -24,12 +24,15 @@ struct Layout {   // offsets into theta, trex_policy.h order
 };
 
 __host__ __device__ inline Layout make_layout(int D, int A) {
+  // every region starts on a multiple of 4 floats (16-byte loads when the kernels stage the parameters in LDS); the
+  // pad elements are ordinary, unused parameters: zero gradient, never read
   Layout l{};
   l.D = D; l.A = A;
   int o = 0;
-  l.pW1 = o; o += D * HID; l.pb1 = o; o += HID; l.pW2 = o; o += HID * HID; l.pb2 = o; o += HID; l.pW3 = o; o += HID * A; l.pb3 = o; o += A;
-  l.vW1 = o; o += D * HID; l.vb1 = o; o += HID; l.vW2 = o; o += HID * HID; l.vb2 = o; o += HID; l.vW3 = o; o += HID; l.vb3 = o; o += 1;
-  l.logstd = o; o += A;
+  auto take = [&](int n) { const int at = o; o = (o + n + 3) & ~3; return at; };
+  l.pW1 = take(D * HID); l.pb1 = take(HID); l.pW2 = take(HID * HID); l.pb2 = take(HID); l.pW3 = take(HID * A); l.pb3 = take(A);
+  l.vW1 = take(D * HID); l.vb1 = take(HID); l.vW2 = take(HID * HID); l.vb2 = take(HID); l.vW3 = take(HID); l.vb3 = take(1);
+  l.logstd = take(A);
   l.count = o;
   return l;
 }
