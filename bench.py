@@ -79,7 +79,24 @@ def _cpu_worker(args):
 
 def cpu_baseline(budget_s=10.0):
     import multiprocessing as mp
-    cores = len(os.sched_getaffinity(0))      # P = the affinity count, uncapped
+    # P = the CPUs this job may use: the affinity count, limited only by the cgroup's CPU quota
+    # where one is set (the GPU box shows 256 hardware threads but grants 16 CPUs: 256 processes were measured there,
+    # 37 k env-steps/s against 51 k with 16 - the quota throttles them - and left the host busy for the GPU section)
+    affinity = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, -(-int(q) // int(per)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = max(1, -(-q // per))
+        except (OSError, ValueError):
+            pass
+    cores = min(affinity, quota) if quota else affinity
     ctx = mp.get_context("spawn")
     with ctx.Pool(cores) as pool:
         one = pool.map(_cpu_worker, [(0, 0.0, "config1")])[0]                       # (i) single core
@@ -100,7 +117,8 @@ def cpu_baseline(budget_s=10.0):
                 break
     except OSError:
         pass
-    return {"value": total / wall, "unit": "env-steps/s", "cores": cores, "cpu_model": cpu_model, "kind": "port",
+    return {"value": total / wall, "unit": "env-steps/s", "cores": cores, "cpu_model": cpu_model,
+            "cpus": {"sched_getaffinity": affinity, "cgroup_cpu_quota": quota}, "kind": "port",
             "sample": "f64 C oracle (oracle/trex_oracle.c), %d processes x 1 env, reset + uniform random "
                       "actions for %.0f s each (%d env-steps total)" % (cores, budget_s, total),
             "config1_zero_action": {
@@ -250,6 +268,8 @@ def main():
     pipe = (sharding.PipelinedGather(env.num_envs, env.rows.shape[1], 1, env.rows.dtype, dev) if force_gather else None)
     gather_mode = ["pipelined"]
 
+    host_times = [] if os.environ.get("TREX_BENCH_DUMP_EVENTS") else None   # diagnostic: when the host had enqueued each timed step
+
     def run(n_steps, t_base, timed=False):
         for t in range(n_steps):
             # HIP events (created before the clock starts) on the stream the kernel is launched on, around every
@@ -259,6 +279,8 @@ def main():
             if ev:
                 ev[0].record()
             env.step_tensor(pool[(t_base + t) % n_draws])
+            if timed and host_times is not None:
+                host_times.append(time.perf_counter())
             if ev:
                 ev[1].record()
                 sampled.append(ev)
@@ -292,7 +314,18 @@ def main():
     # staggered episodes, keyed by the GLOBAL env id: env i starts i * EPISODE_STEPS / N steps into its episode, so
     # that in every step about N / EPISODE_STEPS envs reach the limit and are reset INSIDE the step launch
     env.set_episode_steps(((ids * EPISODE_STEPS) // n_global).to(torch.int32))
-    run(args.preroll, 0)
+    # The runtime frees the records of completed launches lazily, at the first launch AFTER a synchronize: with the
+    # thousand pre-roll launches still on its books, the first TIMED launch (right after the mandatory fence) returned
+    # 0.15 - 0.6 ms late on the host (TREX_BENCH_DUMP_EVENTS=1 prints the enqueue times), the GPU idle meanwhile: six
+    # 20-step runs read 10.36 - 10.95 M. So the pre-roll synchronizes once, 100 steps before its end: the backlog at
+    # the fence is a hundred launches and the first timed launch is enqueued 0.02 ms after the clock starts
+    # (10.61 - 10.80 M over six runs: the same mean, a third of the spread). What remains of the gap to the 300-step
+    # line (11.17 M) is the GPU's: the ~40 launches that follow ANY synchronize run 3 - 4 % slower, and a 20-step
+    # window behind the mandatory fence consists of nothing else.
+    tail = min(100, args.preroll // 2)
+    run(args.preroll - tail, 0)
+    torch.cuda.synchronize()
+    run(tail, args.preroll - tail)
     t_base = args.preroll
     hist0 = contact_hist()   # (before the warm-up: nothing but the mandatory fence sits between warm-up and timing)
     run(args.warmup, t_base)
@@ -325,6 +358,9 @@ def main():
 
     # dominant kernel: average launch duration over the SAME timed region, from the HIP events
     kernel_ms = sum(a.elapsed_time(b) for a, b in sampled) / len(sampled)
+    if host_times and rank == 0:
+        print("host enqueue times of the timed steps [ms after t0]: " + " ".join("%.3f" % ((x - t0) * 1e3) for x in host_times)
+              + " | window %.3f ms" % (dt * 1e3), file=sys.stderr)
     if os.environ.get("TREX_BENCH_DUMP_EVENTS") and rank == 0:   # per-launch durations of the timed region (diagnostic)
         print("kernel ms per sampled timed step: " + " ".join("%.4f" % a.elapsed_time(b) for a, b in sampled), file=sys.stderr)
     finite = bool(torch.isfinite(env.obs).all().item())

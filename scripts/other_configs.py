@@ -34,33 +34,6 @@ for name, n, extra in cases:
                                                              d["state_mix"]["mean_contacts"][-1]))
     print(rows[-1], flush=True)
 
-# config 3: PPO-driven, learner included
-code = r'''
-import sys, time, torch
-sys.path.insert(0, "trex-gym_amd")
-from trex_gym.trex_train import build_environment
-from trex_gym.ppo import PPO
-for graphs in (False, True):
-    env = build_environment(4096)
-    agent = PPO(env, nsteps=32, nminibatches=32, noptepochs=4, seed=0, use_graphs=graphs)
-    for _ in range(3):
-        agent.update(agent.collect())
-    torch.cuda.synchronize(); t0 = time.perf_counter(); s0 = agent.total_env_steps
-    tr = 0.0
-    for _ in range(10):
-        t1 = time.perf_counter(); b = agent.collect(); torch.cuda.synchronize(); tr += time.perf_counter() - t1
-        agent.update(b)
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print("PPO graphs=%d %.0f %.0f" % (graphs, (agent.total_env_steps - s0) / dt, (agent.total_env_steps - s0) / tr), flush=True)
-'''
-r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
-rows += ["", "PPO-driven (config 3; 4096 envs, nsteps 32, 4 epochs x 32 minibatches, policy + learner on the same GPU):", ""]
-for l in r.stdout.splitlines():
-    if l.startswith("PPO"):
-        _, g, total, roll = l.split()
-        rows.append("* %s: %.0f k env-steps/s including the learner; rollout alone (policy + env step + normalisation) %.0f k env-steps/s"
-                    % ("HIP-graph replay" if g.endswith("1") else "eager", float(total) / 1e3, float(roll) / 1e3))
-if r.returncode:
-    rows.append("PPO run failed: " + r.stderr[-400:].replace("\n", " "))
+# config 3 (PPO-driven, learner included): scripts/ppo_rate.py -> <tag>_ppo_rate.txt
 open(out, "w").write("\n".join(rows) + "\n")
 print("\n".join(rows))
