@@ -1,7 +1,18 @@
-"""gym.spaces.Box when gym is installed; otherwise a minimal stand-in with the attributes PPO code
-reads (low, high, shape, dtype, sample, contains). The reference builds
-spaces.Box(low=..., high=..., dtype=np.float32) at trex_env.py:93-96."""
+"""gym.spaces.Box / gym.Env when gym is installed; otherwise minimal stand-ins: a Box with the attributes PPO code
+reads (low, high, shape, dtype, sample, contains) and an empty Env base. The reference derives its env from gym.Env
+(trex_env.py:25) and builds spaces.Box(low=..., high=..., dtype=np.float32) at trex_env.py:93-96; TrexBulletEnv and
+TrexVecEnv derive from `Env` below, so that isinstance(env, gym.Env) holds wherever gym exists."""
 import numpy as np
+
+try:  # pragma: no cover - gym is not in this image
+    from gym import Env  # type: ignore
+except Exception:  # noqa: BLE001
+
+    class Env:
+        """Stand-in for gym.Env (gym absent): the old-gym surface the reference uses is implemented by the subclasses."""
+        metadata = {"render.modes": []}
+        reward_range = (-float("inf"), float("inf"))
+        spec = None
 
 try:  # pragma: no cover - gym is not in this image
     from gym.spaces import Box  # type: ignore

@@ -18,7 +18,7 @@ RENDER_HEIGHT = 720
 RENDER_WIDTH = 960
 
 
-class TrexBulletEnv:
+class TrexBulletEnv(spaces.Env):     # gym.Env where gym is importable (trex_env.py:25)
     metadata = {
         "render.modes": ["human", "rgb_array"],
         "video.frames_per_second": 50

@@ -23,7 +23,7 @@ from . import _capi, sharding, spaces
 REWARD_DEFAULTS = dict(distance_weight=1.0, energy_weight=0.005, drift_weight=0.002)  # trex_env.py:42-44
 
 
-class TrexVecEnv:
+class TrexVecEnv(spaces.Env):       # gym.Env where gym is importable; the surface is baselines' VecEnv
     metadata = {"render.modes": ["human", "rgb_array"], "video.frames_per_second": 50}  # trex_env.py:33-36
 
     def __init__(self, num_envs, urdf_path=None, collisions_dir=None, device=None, action_repeat=1,
