@@ -65,3 +65,24 @@ def test_reference_preset_learns():
     assert -330.0 < r[0] < -250.0                      # the untrained policy: the lifting penalty of the start pose
     assert sum(r[-3:]) / 3 > sum(r[:3]) / 3 + 100.0    # measured: -292 -> about -100 after 12 updates
     assert r[-1] > r[0] + 120.0
+
+
+def test_reference_batch_size_and_a_long_horizon():
+    """The reference collects nsteps = 4096 samples of ONE env per update (trex_train.py:51). The batched trainer reaches
+    the same 4 096 samples per update with 32 envs x 128 steps (32 envs = one MFMA tile; minibatches of 128 samples as
+    in the reference: 4096 / 32), and a horizon of 1 024 steps (32 768 samples, GAE over 1 024 steps with episode ends
+    inside it) runs through the same kernels."""
+    from trex_gym import trex_train
+    from trex_gym.ppo import PPO
+    env = trex_train.build_environment(32, max_episode_steps=100)
+    agent = PPO(env, nsteps=128, seed=0, **dict(trex_train.PRESETS["reference"], noptepochs=4))
+    hist = agent.learn(32 * 128 * 6, log=None)
+    assert len(hist) == 6 and all(math.isfinite(h[k]) for h in hist for k in ("policy_loss", "value_loss", "entropy", "mean_step_reward"))
+    assert hist[-1]["value_loss"] < hist[0]["value_loss"]
+    env2 = trex_train.build_environment(32, max_episode_steps=300)
+    long = PPO(env2, nsteps=1024, nminibatches=32, noptepochs=2, seed=0)
+    obs, act, logp, val, adv, ret, mean_rew = long.collect()
+    assert obs.shape == (32 * 1024, 75) and torch.isfinite(adv).all() and torch.isfinite(ret).all() and math.isfinite(mean_rew)
+    assert float(long.b_done.sum()) >= 32 * 3          # three episode ends per env inside the horizon
+    info = long.update((obs, act, logp, val, adv, ret, mean_rew))
+    assert all(math.isfinite(v) for v in info.values()) and torch.isfinite(long.policy.theta).all()
