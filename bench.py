@@ -195,6 +195,10 @@ def main():
                     help="0 (default, SURVEY 8d): a FRESH uniform draw for every env and every pre-roll / warm-up / timed step, "
                          "pre-generated into one [T, n, 25] tensor in HBM; C > 0: rounds 1-2's input, C draws per env, cycled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher check without a GPU (tests/test_bench_launcher.py): the ranks rendezvous over gloo, gather one "
+                         "row block of CPU tensors through trex_gym.sharding and rank 0 prints a JSON line marked dry_run; nothing is timed")
+    ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help="with --dry-run: this rank exits with code 3 (failure relay check)")
     ap.add_argument("--collision", choices=["hulls", "primitives"], default="hulls",
                     help="primitives: capsules/spheres fitted to the hulls (148 points instead of 2181 vertices); not the headline config")
     ap.add_argument("--domain-rand", action="store_true",
@@ -212,6 +216,27 @@ def main():
         if "RANK" not in os.environ and args.gpus > 1:
             _self_launch(args.gpus, sys.argv[1:])     # never returns; nothing GPU-related has been imported yet
         args.gpus = world
+
+    if args.dry_run:
+        import torch
+        import torch.distributed as dist
+        from trex_gym import sharding      # (device-agnostic: does not load the HIP library)
+        if rank == args.dry_run_fail_rank:
+            sys.exit(3)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        lo, hi = sharding.shard_range(8 * world, rank, world)
+        local = sharding.pack_rows(torch.arange(lo, hi, dtype=torch.float32).reshape(-1, 1).repeat(1, 3),
+                                   torch.full((hi - lo,), float(rank)), torch.zeros(hi - lo))
+        rows = sharding.all_gather_rows(local, 8 * world, world)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "metric": "launcher check (no GPU, nothing timed)", "value": None, "n_gpus": world,
+                              "gathered_rows": int(rows.shape[0]), "row_sum": float(rows[:, 0].sum())}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
