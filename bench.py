@@ -194,6 +194,9 @@ def main():
     ap.add_argument("--action-cycle", type=int, default=0,
                     help="0 (default, SURVEY 8d): a FRESH uniform draw for every env and every pre-roll / warm-up / timed step, "
                          "pre-generated into one [T, n, 25] tensor in HBM; C > 0: rounds 1-2's input, C draws per env, cycled")
+    ap.add_argument("--steps-per-launch", type=int, default=1,
+                    help="S > 1 (NOT the headline; one GPU): trex_batch_step_many, S env-steps of every env per launch - what an "
+                         "open-loop action sequence allows: no wave waits for the slowest wave of a step. --steps must be a multiple of S")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check without a GPU (tests/test_bench_launcher.py): the ranks rendezvous over gloo, gather one "
@@ -295,7 +298,24 @@ def main():
 
     host_times = [] if os.environ.get("TREX_BENCH_DUMP_EVENTS") else None   # diagnostic: when the host had enqueued each timed step
 
+    S = args.steps_per_launch
+    if S > 1:
+        if world > 1 or args.steps % S or args.action_cycle:
+            sys.exit("--steps-per-launch: one GPU, fresh draws, --steps a multiple of S")
+        many_rows = torch.empty(S, n_local, env.rows.shape[1], device=dev)
+
     def run(n_steps, t_base, timed=False):
+        if S > 1 and timed:
+            # (S env-steps per launch; the events bracket every launch: there are few)
+            for t in range(0, n_steps, S):
+                ev = events[t // S] if t // S < len(events) else None
+                if ev:
+                    ev[0].record()
+                env.batch.step_many(pool[t_base + t: t_base + t + S], many_rows)
+                if ev:
+                    ev[1].record()
+                    sampled.append(ev)
+            return
         for t in range(n_steps):
             # HIP events (created before the clock starts) on the stream the kernel is launched on, around every
             # EVENT_STRIDE-th launch of the timed region: a timing event costs the stream about 4 us, two around EVERY
@@ -383,19 +403,21 @@ def main():
 
     # dominant kernel: average launch duration over the SAME timed region, from the HIP events
     kernel_ms = sum(a.elapsed_time(b) for a, b in sampled) / len(sampled)
+    if S > 1:
+        kernel_ms /= S        # per env-step: the figures below are per step of every env
     if host_times and rank == 0:
         print("host enqueue times of the timed steps [ms after t0]: " + " ".join("%.3f" % ((x - t0) * 1e3) for x in host_times)
               + " | window %.3f ms" % (dt * 1e3), file=sys.stderr)
     if os.environ.get("TREX_BENCH_DUMP_EVENTS") and rank == 0:   # per-launch durations of the timed region (diagnostic)
         print("kernel ms per sampled timed step: " + " ".join("%.4f" % a.elapsed_time(b) for a, b in sampled), file=sys.stderr)
-    finite = bool(torch.isfinite(env.obs).all().item())
+    finite = bool(torch.isfinite(many_rows if S > 1 else env.obs).all().item())
     info = env.batch.launch_info()
     build_id = _capi.build_id()
     if rank == 0:
         alg = (info["alg_bytes_per_env_step"] + (1044 if args.domain_rand else 0)) * n_local  # bytes per launch
         achieved = alg / (kernel_ms * 1e-3) / 1e9
         # PMC-derived numbers are only quoted when they were collected on THIS kernel build and workload
-        headline = args.envs_per_gpu == 4096 and not overrides and not args.domain_rand and args.action_cycle == 0
+        headline = args.envs_per_gpu == 4096 and not overrides and not args.domain_rand and args.action_cycle == 0 and S == 1
         tj, sj = _load_json("pmc_traffic.json"), _load_json("sq_counters.json")
         traffic = tj["hbm_bytes_per_launch"] if (tj and headline and tj.get("build_id") == build_id) else None
         traffic_note = ("PMC FETCH_SIZE x2 + WRITE_SIZE (MI355X_MICROARCH.md), collected on build %s by "
@@ -440,12 +462,14 @@ def main():
                                       EPISODE_STEPS, args.preroll,
                                       ", [obs|reward|done] all-gather over RCCL each step, overlapped with the next step (gathered rows are one step old)" if world > 1 else ""),
                        "envs_global": n_global, "parallelism": "env-sharded dp%d" % world,
+                       **({"NOT_THE_HEADLINE_steps_per_launch": S, "launch": "trex_batch_step_many: %d env-steps of every env per launch "
+                                   "(open-loop action sequence); kernel_ms and the roofline figures are per env-step" % S} if S > 1 else {}),
                        **({"domain_randomisation": "mass_scale U(0.8,1.2) per body, friction U(0.5,1.25), seed 1"}
                           if args.domain_rand else {}),
                        **({"ABLATION_param_overrides": overrides} if overrides else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel": "trex_step_kernel<false, false>", "kernel_ms": kernel_ms,
+                         "kernel": "trex_step_many_kernel" if S > 1 else "trex_step_kernel<false, false>", "kernel_ms": kernel_ms,
                          "kernel_ms_covers": "one step launch = ONE kernel, trex_step_kernel<false, false> (it ranks the envs for the next launch and "
                                              "resets the envs whose episode ends), bracketed by HIP events; every %d-th launch of the timed region is bracketed (%d samples)" % (stride, len(sampled)),
                          "alg_bytes_per_launch": alg, "kernel_build": build_id,

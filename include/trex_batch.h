@@ -149,6 +149,18 @@ int trex_batch_step_rows(TrexBatch *batch, const float *actions_dev, float *rows
                          float *penalties_dev, uint8_t *done_dev, void *stream);
 int trex_batch_reset_rows(TrexBatch *batch, const uint8_t *mask_dev, float *rows_dev, int row_stride, void *stream);
 
+/* num_steps env-steps of every env in ONE launch, for action sequences that are known in advance (open-loop rollouts:
+ * random-action benchmarks, sampling-based planners, replaying recorded actions): step s reads actions_dev[s] and writes
+ * the row block rows_dev[s] -
+ *   actions_dev [S, N, J] f32, rows_dev [S, N, row_stride] f32 (obs | reward | done per row, as trex_batch_step_rows),
+ *   penalties_dev [S, N, 3] and done_dev [S, N] u8 nullable.
+ * Results are BITWISE those of num_steps trex_batch_step_rows calls (episode limit and containment included: tested).
+ * Why it exists: with one step per launch every SIMD waits for the launch's slowest wave - a fifth of the launch at 4 096
+ * envs -, here a wave goes straight on to its env's next step and the env's state stays on the chip between steps. A
+ * closed loop (a policy that needs step s's observations for step s + 1's actions) cannot use it. */
+int trex_batch_step_many(TrexBatch *batch, const float *actions_dev, float *rows_dev, int row_stride, int num_steps,
+                         float *penalties_dev, uint8_t *done_dev, void *stream);
+
 /* Episode limit of the harness. The reference env never terminates (should_terminate() is constant False,
  * trex_env.py:183-184); a training harness cuts episodes (gym's TimeLimit; baselines' VecEnv then resets the env
  * and returns the first observation of the new episode with done = True). With max_episode_steps > 0 the STEP

@@ -19,6 +19,8 @@ hipError_t trex_launch_step(const TrexDeviceModel *, TrexBatchArrays, int, const
                             float *, float, float, float, float *, hipStream_t, float *, int, int, int);
 hipError_t trex_launch_reset(const TrexDeviceModel *, TrexBatchArrays, int, const uint8_t *, float *, float, float,
                              float, float *, hipStream_t, int, float *, float *, int);
+hipError_t trex_launch_step_many(const TrexDeviceModel *, TrexBatchArrays, int, const float *, float *, int, int, float *, uint8_t *,
+                                 float, float, float, hipStream_t, int, int);
 hipError_t trex_launch_pack_state(const TrexDeviceModel *, TrexBatchArrays, int, float *, int, hipStream_t);
 hipError_t trex_launch_head(const TrexDeviceModel *, TrexBatchArrays, int, float *, hipStream_t);
 hipError_t trex_launch_link_transforms(const TrexDeviceModel *, TrexBatchArrays, int, float *, hipStream_t, int);
@@ -543,6 +545,23 @@ int trex_batch_step_rows(TrexBatch *b, const float *actions_dev, float *rows_dev
   float *rew = rows_dev + 3 * b->nj;
   HIP_TRY(trex_launch_step(b->dmodel, b->arr, b->n, actions_dev, rows_dev, rew, done_dev, penalties_dev, b->wd, b->we,
                            b->wk, nullptr, (hipStream_t)stream, rew + 1, row_stride, row_stride, b->balance()));
+  return TREX_OK;
+}
+
+int trex_batch_step_many(TrexBatch *b, const float *actions_dev, float *rows_dev, int row_stride, int num_steps,
+                         float *penalties_dev, uint8_t *done_dev, void *stream) {
+  if (check_batch(b)) return TREX_E_INVALID;
+  if (!actions_dev || !rows_dev) return fail(TREX_E_INVALID, "trex_batch_step_many: null argument");
+  if (num_steps < 1) return fail(TREX_E_INVALID, "trex_batch_step_many: num_steps must be >= 1");
+  if (row_stride < 3 * b->nj + 2) return fail(TREX_E_INVALID, "trex_batch_step_many: row_stride < 3J + 2");
+  DeviceGuard guard(b->device);
+  const size_t n = (size_t)b->n, S = (size_t)num_steps;
+  BUF_TRY(actions_dev, S * n * b->nj * sizeof(float), "trex_batch_step_many: actions");
+  BUF_TRY(rows_dev, ((S * n - 1) * row_stride + 3 * b->nj + 2) * sizeof(float), "trex_batch_step_many: rows");
+  BUF_TRY(penalties_dev, S * n * 3 * sizeof(float), "trex_batch_step_many: penalties");
+  BUF_TRY(done_dev, S * n, "trex_batch_step_many: done");
+  HIP_TRY(trex_launch_step_many(b->dmodel, b->arr, b->n, actions_dev, rows_dev, row_stride, num_steps, penalties_dev, done_dev,
+                                b->wd, b->we, b->wk, (hipStream_t)stream, b->balance(), b->nj));
   return TREX_OK;
 }
 

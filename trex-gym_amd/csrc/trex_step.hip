@@ -359,14 +359,21 @@ struct KernelArgs {
   int32_t *bal;               // rank lists of the wave balance (step launches), nullable = workgroup k runs env k
   float w_distance, w_energy, w_drift;
   float *debug;           // diagnostics of env 0's last substep (tests), nullable
+  // MULTI launches (trex_batch_step_many): n_steps env-steps per launch; step s reads actions + s * N * J and writes the
+  // row block at + s * step_rows floats (obs, reward, done_f alike), done bytes at + s * N, penalties at + s * 3 N
+  int n_steps;
+  long long step_rows;
 };
 
 }  // namespace
 
 // DEBUG instantiations carry the diagnostics dump (scripts/gpu_debug.py, phase stamps); the product launches
 // use DEBUG = false so that none of the dump's address arithmetic exists in the shipped kernels.
-template <bool RESET, bool DEBUG>
-__global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
+// MULTI: the launch advances every env by args.n_steps env-steps (open-loop action sequences): the state stays in
+// SGPRs / LDS between the steps and - what it is for - no wave ever waits for the slowest wave of a step: with one step
+// per launch the SIMDs idle a fifth of the launch behind its heaviest envs.
+template <bool RESET, bool DEBUG, bool MULTI>
+__device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
   __shared__ WaveLds W;
   const int tid = threadIdx.x;
   const TrexDeviceModel *__restrict__ M = args.model;
@@ -476,10 +483,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
 #pragma unroll
     for (int k = 0; k < 4; k++) badl |= !(fabsf(quat[k]) < 3.0e38f);
     bad = __ballot(badl) != 0ull;
-    if (!RESET && is_joint) {
-      const float a = args.actions[(size_t)env * nj + M->obs_slot[tid]];
-      target = fminf(fmaxf(a, M->lower[tid]), M->upper[tid]);  // np.clip, trex_env.py:147
-    }
+    (void)is_joint;   // (the action -> joint target of an env-step is read at the top of the step loop below)
     if (tid < TL) {
       W.st[ST_Q][tid] = q; W.st[ST_QD][tid] = qd; W.st[ST_TAU][tid] = mtau; W.st[ST_TARGET][tid] = target;
       W.st[ST_NQD][tid] = 0.f;
@@ -585,11 +589,6 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
   // one of the new episode (baselines' VecEnv semantics) and no separate reset launch sits between two steps.
   int age = 0;
   bool time_up = false;
-  if (!RESET && args.arr.max_episode_steps > 0) {
-    age = steps_in + 1;
-    time_up = age >= args.arr.max_episode_steps;
-  }
-  const int n_total = n_sub + ((!RESET && time_up) ? 1 : 0);
   bool env_bad = false;
   float lift = 0.f, drift = 0.f, energy = 0.f;
   // the end of an env-step: head position (needs FK at the new pose: getLinkState(computeForwardKinematics=1)), reward
@@ -641,6 +640,30 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
     }
     __syncthreads();
   };
+  const int n_launch_steps = MULTI ? args.n_steps : 1;
+#pragma unroll 1
+  for (int ls = 0; ls < n_launch_steps; ls++) {
+  // ================================================================ one env-step
+  if (!RESET) {
+    // the joint targets of this step: clip(action) (np.clip, trex_env.py:147), parked per body lane
+    const int l = lane_id();
+    if (l < TL) {
+      float target = 0.f;
+      if (l >= 1 && l < nb) {
+        const TrexDeviceModel *Mi = Mo();
+        const float a = args.actions[((size_t)(MULTI ? ls : 0) * args.n_envs + env) * nj + Mi->obs_slot[l]];
+        target = fminf(fmaxf(a, Mi->lower[l]), Mi->upper[l]);
+      }
+      W.st[ST_TARGET][l] = target;
+    }
+    if (MULTI && ls > 0) { motors_on = true; bad = false; env_bad = false; }
+  }
+  age = 0; time_up = false;
+  if (!RESET && args.arr.max_episode_steps > 0) {
+    age = steps_in + 1;
+    time_up = age >= args.arr.max_episode_steps;
+  }
+  const int n_total = n_sub + ((!RESET && time_up) ? 1 : 0);
 #pragma unroll 1
   for (int sub = 0; sub < n_total; sub++) {
     if (!RESET && sub == n_sub) {   // time is up: the step is complete, the new episode starts (settle substep follows)
@@ -1892,24 +1915,51 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
 #undef REROW
   }
 
-  // ---- epilogue
+  // ---- end of the env-step: outputs
   if (RESET || !time_up) finish_step();
   if (env_bad && !time_up) to_start_pose();     // (a time-limit reset already left a sound state)
+  const int steps_out = (RESET || args.arr.max_episode_steps > 0) ? ((RESET || time_up || env_bad) ? 0 : age) : steps_in;
+  {
+    const int lt = lane_id();
+    const int bl = lt & (TL - 1);
+    const bool is_joint = lt >= 1 && lt < nb;
+    const size_t so = MULTI ? (size_t)ls * (size_t)args.step_rows : 0;      // this step's row block
+    if (args.obs && is_joint) {
+      const float q = W.st[ST_Q][bl], qd = W.st[ST_QD][bl], mtau = W.st[ST_TAU][bl];
+      float *o = args.obs + so + (size_t)env * args.obs_stride;
+      const int obs_slot = M->obs_slot[bl];
+      o[obs_slot] = q; o[nj + obs_slot] = qd; o[2 * nj + obs_slot] = mtau;
+    }
+    if (lt == 0) {
+      // (RESET launches carry the reward / done pointers only for trex_batch_reset_rows: the env that was reset
+      // starts its episode with reward 0, done 0 in the caller's row block)
+      if (args.reward) args.reward[so + (size_t)env * args.scal_stride] = (RESET || env_bad) ? 0.f : -lift - drift - energy;
+      // should_terminate() is constant False (trex_env.py:183-184): done only flags the harness's episode limit and
+      // a contained non-finite env
+      if (args.done) args.done[(size_t)(MULTI ? ls : 0) * args.n_envs + env] = (!RESET && (env_bad || time_up)) ? 1 : 0;
+      if (args.done_f) args.done_f[so + (size_t)env * args.scal_stride] = (!RESET && (env_bad || time_up)) ? 1.f : 0.f;
+      if (args.penalties) {
+        float *pn = args.penalties + ((size_t)(MULTI ? ls : 0) * args.n_envs + env) * 3;
+        pn[0] = env_bad ? 0.f : lift; pn[1] = env_bad ? 0.f : drift; pn[2] = env_bad ? 0.f : energy;
+      }
+    }
+  }
+  steps_in = steps_out;
+  }   // the env-steps of this launch
+
+  // ---- epilogue: the state goes back to HBM
   const int lt = lane_id();
   const int bl = lt & (TL - 1);
-  const bool is_joint = lt >= 1 && lt < nb;
   float q = W.st[ST_Q][bl], qd = W.st[ST_QD][bl], mtau = W.st[ST_TAU][bl];
   if (lt >= TL) { q = 0.f; qd = 0.f; mtau = 0.f; }
-  // ---- write back
   const bool store_state = RESET ? do_reset : true;
   if (store_state) {
     // base row: pos(3) quat(4) v(3) w(3); lane k < 13 stores word k (static selects: a dynamically indexed
     // register array would be demoted to scratch memory)
     float *b = args.arr.base + (size_t)env * 16;
     // ... + contact count | motors flag, summed normal impulse, episode steps: the whole 64-byte line in one store
-    const int steps_out = (RESET || args.arr.max_episode_steps > 0) ? ((RESET || time_up || env_bad) ? 0 : age) : steps_in;
     const float row[16] = {pos[0], pos[1], pos[2], quat[0], quat[1], quat[2], quat[3], bv[0], bv[1], bv[2], bw[0], bw[1], bw[2],
-                           __int_as_float((stat_nc & 255) | (motors_on ? TREX_MOTORS_BIT : 0)), stat_imp, __int_as_float(steps_out)};
+                           __int_as_float((stat_nc & 255) | (motors_on ? TREX_MOTORS_BIT : 0)), stat_imp, __int_as_float(steps_in)};
     float word = row[0];
 #pragma unroll
     for (int k = 1; k < 16; k++) word = (lt == k) ? row[k] : word;
@@ -1920,23 +1970,7 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
       args.arr.tau[(size_t)env * TL + lt] = mtau;
     }
   }
-  if (args.obs && is_joint) {
-    float *o = args.obs + (size_t)env * args.obs_stride;
-    const int obs_slot = M->obs_slot[bl];
-    o[obs_slot] = q; o[nj + obs_slot] = qd; o[2 * nj + obs_slot] = mtau;
-  }
   if (lt == 0) {
-    // (RESET launches carry the reward / done pointers only for trex_batch_reset_rows: the env that was reset
-    // starts its episode with reward 0, done 0 in the caller's row block)
-    if (args.reward) args.reward[(size_t)env * args.scal_stride] = (RESET || env_bad) ? 0.f : -lift - drift - energy;
-    // should_terminate() is constant False (trex_env.py:183-184): done only flags the harness's episode limit and
-    // a contained non-finite env
-    if (args.done) args.done[env] = (!RESET && (env_bad || time_up)) ? 1 : 0;
-    if (args.done_f) args.done_f[(size_t)env * args.scal_stride] = (!RESET && (env_bad || time_up)) ? 1.f : 0.f;
-    if (args.penalties) {
-      args.penalties[env * 3 + 0] = env_bad ? 0.f : lift; args.penalties[env * 3 + 1] = env_bad ? 0.f : drift;
-      args.penalties[env * 3 + 2] = env_bad ? 0.f : energy;
-    }
     if (!RESET && args.bal) {
       // file this env under its contact count for the next launch (the other phase's lists); the LAST wave of the
       // launch - every wave has read the phase and filed its env by then - clears the counts this launch read and
@@ -1956,6 +1990,11 @@ __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) {
     }
   }
 }
+
+template <bool RESET, bool DEBUG>
+__global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) { trex_step_body<RESET, DEBUG, false>(args); }
+// S env-steps per launch (trex_batch_step_many)
+__global__ __launch_bounds__(64, 4) void trex_step_many_kernel(KernelArgs args) { trex_step_body<false, false, true>(args); }
 
 // ---------------------------------------------------------------- small utility kernels
 __global__ void trex_pack_state_kernel(const TrexDeviceModel *M, TrexBatchArrays arr, int n, float *out, int pack) {
@@ -2137,6 +2176,18 @@ hipError_t trex_launch_step(const TrexDeviceModel *model, TrexBatchArrays arr, i
   if (debug) hipLaunchKernelGGL((trex_step_kernel<false, true>), dim3(n), dim3(64), 0, stream, a);
   else hipLaunchKernelGGL((trex_step_kernel<false, false>), dim3(n), dim3(64), 0, stream, a);
 #endif
+  return hipGetLastError();
+}
+
+// S env-steps per launch (open-loop action sequences): actions [S, N, J], rows [S, N, row_stride] = obs | reward | done,
+// penalties [S, N, 3] and done bytes [S, N] nullable
+hipError_t trex_launch_step_many(const TrexDeviceModel *model, TrexBatchArrays arr, int n, const float *actions, float *rows,
+                                 int row_stride, int n_steps, float *penalties, uint8_t *done, float wd, float we, float wk,
+                                 hipStream_t stream, int balance, int nj) {
+  float *rew = rows + 3 * nj;
+  KernelArgs a{model, arr, n, actions, rows, rew, done, rew + 1, row_stride, row_stride, penalties, nullptr,
+               balance ? arr.balance : nullptr, wd, we, wk, nullptr, n_steps, (long long)n * row_stride};
+  hipLaunchKernelGGL(trex_step_many_kernel, dim3(n), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
 

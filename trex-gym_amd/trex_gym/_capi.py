@@ -39,7 +39,7 @@ SYMBOLS = [
     "trex_build_id", "trex_batch_step_rows", "trex_batch_reset_rows",
     "trex_batch_set_episode_limit", "trex_batch_get_episode_steps",
     "trex_batch_set_wave_balance", "trex_batch_forget_buffers",
-    "trex_model_num_visuals", "trex_model_visual_info", "trex_batch_visual_transforms",
+    "trex_model_num_visuals", "trex_model_visual_info", "trex_batch_visual_transforms", "trex_batch_step_many",
 ]
 
 # every symbol include/trex_policy.h declares (the trainer-side kernels)
@@ -76,6 +76,7 @@ lib.trex_batch_set_reward_weights.argtypes = [_vp, C.c_float, C.c_float, C.c_flo
 lib.trex_batch_reset.argtypes = [_vp, _vp, _vp, _vp]
 lib.trex_batch_step.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp]
 lib.trex_batch_step_rows.argtypes = [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp]
+lib.trex_batch_step_many.argtypes = [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]
 lib.trex_batch_reset_rows.argtypes = [_vp, _vp, _vp, C.c_int, _vp]
 lib.trex_batch_set_episode_limit.argtypes = [_vp, C.c_int, _vp, _vp]
 lib.trex_batch_get_episode_steps.argtypes = [_vp, _vp, _vp]
@@ -324,6 +325,19 @@ class Batch:
                                        self._p(rows, "float32", n * (3 * J + 2), "rows"), int(rows.shape[1]),
                                        self._p(penalties, "float32", 3 * n, "penalties"),
                                        _ptr(done, self.device, None, n, "done"), self._stream(stream)))
+
+    def step_many(self, actions, rows, penalties=None, done=None, stream=None):
+        """S env-steps in one launch: actions [S, n, J], rows [S, n, stride] (obs | reward | done per row)."""
+        import torch
+        n, J, S = self.num_envs, self.J, int(actions.shape[0])
+        if done is not None and done.dtype not in (torch.uint8, torch.bool):
+            raise TrexError(E_INVALID, "done: expected dtype uint8 or bool, got %s" % done.dtype)
+        if rows.dim() != 3 or int(rows.shape[0]) != S or int(rows.shape[1]) != n:
+            raise TrexError(E_INVALID, "rows: expected shape [%d, %d, >= %d], got %s" % (S, n, 3 * J + 2, tuple(rows.shape)))
+        check(lib.trex_batch_step_many(self.h, self._p(actions, "float32", S * n * J, "actions"),
+                                       self._p(rows, "float32", (S * n - 1) * rows.shape[2] + 3 * J + 2, "rows"), int(rows.shape[2]), S,
+                                       self._p(penalties, "float32", 3 * S * n, "penalties"), _ptr(done, self.device, None, S * n, "done"),
+                                       self._stream(stream)))
 
     def reset_rows(self, rows, mask=None, stream=None):
         n, J = self.num_envs, self.J

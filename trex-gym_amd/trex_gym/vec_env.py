@@ -115,6 +115,22 @@ class TrexVecEnv(spaces.Env):       # gym.Env where gym is importable; the surfa
         self.batch.step_rows(actions, self.rows, self.penalties, done=self.done)
         return self.obs, self.rew, self.done
 
+    def step_many_tensor(self, actions, rows=None):
+        """Open-loop rollout: actions [S, n, J] f32 on device -> rows [S, n, 3J+2] (obs | reward | done of every step), S
+        env-steps in ONE launch (trex_batch_step_many; bitwise S calls of step_tensor). `rows`, `obs`, `rew`, `done_f`
+        and `done` then hold the last step. sharding.split_rows(rows[s]) cuts a step's block into the three."""
+        if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self.device:
+            actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
+        if actions.dim() != 3 or tuple(actions.shape[1:]) != (self.num_envs, self.J):
+            raise ValueError("actions must have shape (S, %d, %d), got %s" % (self.num_envs, self.J, tuple(actions.shape)))
+        S = int(actions.shape[0])
+        if rows is None:
+            rows = torch.empty(S, self.num_envs, 3 * self.J + 2, device=self.device)
+        self.batch.step_many(actions, rows)
+        self.rows.copy_(rows[-1])
+        self.done.copy_(self.done_f != 0)
+        return rows
+
     def _point_at(self, k):
         J = self.J
         self._row_k = k
