@@ -21,6 +21,8 @@ TREX_LIB=$PWD/trex-gym_amd/trex_gym/libtrex_hip_stamps.so python scripts/wave_ph
 python scripts/parity_stats.py 2>&1 | grep -v amdgpu.ids > $OUT/parity_stats.txt
 python scripts/ppo_rate.py 4 2>&1 | grep PPO > $OUT/ppo_rate.txt
 python scripts/ppo_rate.py 32 2>&1 | grep PPO >> $OUT/ppo_rate.txt
+python scripts/ppo_signal.py 4096 32 150 32 1 32 2>&1 | grep -v amdgpu.ids > $OUT/ppo_learning_curve.txt || echo "ppo_signal failed"
+for S in 10 30; do python bench.py --steps 300 --warmup 30 --no-cpu-baseline --steps-per-launch $S > $OUT/bench_300_spl$S.json 2> $OUT/bench_300_spl$S.err; done
 python scripts/other_configs.py $OUT/other_configs.md > $OUT/other_configs.log 2>&1 || echo "other_configs failed"
 python scripts/soak.py 20000 2>&1 | grep -v amdgpu.ids > $OUT/soak.txt || echo "soak failed"
 ./profiles/tools/row_bench > $OUT/row_bench.txt 2>&1 || true

@@ -99,7 +99,8 @@ json.dump({"build_id": build, "tag": tag, "envs": 4096, "valu_insts_per_launch":
 for src, dst in (("bench_300.json", "bench_line.json"), ("bench_256.json", "bench_line_256envs.json"), ("bench_20.json", "bench_line_20steps.json"), ("bench_trace.json", "bench_line_profiled.json"),
                  ("bench_300_cycle16.json", "bench_line_cycle16.json"), ("bench_20_cycle16.json", "bench_line_cycle16_20steps.json"),
                  ("parity_stats.txt", "parity_stats_head.txt"), ("ppo_rate.txt", "ppo_rate.txt"), ("other_configs.md", "other_configs.md"),
-                 ("soak.txt", "soak.txt"),
+                 ("soak.txt", "soak.txt"), ("ppo_learning_curve.txt", "ppo_learning_curve.txt"),
+                 ("bench_300_spl10.json", "bench_line_steps_per_launch10.json"), ("bench_300_spl30.json", "bench_line_steps_per_launch30.json"),
                  ("wave_phases_4096.txt", "wave_phases_4096.txt"), ("wave_phases_256.txt", "wave_phases_256.txt"),
                  ("row_bench.txt", "row_bench.txt"), ("census.txt", "census.txt")):
     if os.path.exists(P + "/" + src):
