@@ -1,0 +1,69 @@
+"""The N > 1 path on real kernels (one-GPU box: two rank processes share the GPU, gloo carries the collective - RCCL
+refuses two ranks per device): env-id sharding + the in-place pipelined all-gather of the [obs | reward | done] row block
+(sharding.PipelinedGather, the form bench.py --gpus N times) against a single-process run of the same global batch.
+Bitwise: envs are independent and the actions are keyed by the GLOBAL env id."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ASSET_URDF, ROOT
+
+pytestmark = pytest.mark.gpu
+N_GLOBAL, STEPS = 16, 7
+
+
+def _actions(model_lo, model_hi, ids, t, dev):
+    from trex_gym import sharding
+    return sharding.synthetic_actions(ids, t, model_lo, model_hi, seed=0, device=dev)
+
+
+def _rank(rank, world, port, ret):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "trex-gym_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from trex_gym.vec_env import TrexVecEnv
+    dev = torch.device("cuda", 0)
+    env = TrexVecEnv(N_GLOBAL, urdf_path=ASSET_URDF, device=dev, rank=rank, world_size=world, max_episode_steps=4, row_buffers=2)
+    env.reset_tensor()
+    ids = torch.arange(env.env_lo, env.env_hi, device=dev)
+    got = []
+    for t in range(STEPS):
+        env.step_tensor(_actions(env.model.lower, env.model.upper, ids, t, dev))
+        prev = env.all_gather_rows_pipelined(wait=False)       # bench.py's call: in place, no consumer-side wait
+        got.append(None if prev is None else prev.clone().cpu())
+    got.append(env._pipe.flush().clone().cpu())
+    blocking = env.all_gather_rows().clone().cpu()              # the blocking form: this step's rows
+    if rank == 1:
+        ret["got"], ret["blocking"] = got, blocking
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_the_gpu_gather_what_one_process_computes():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "trex-gym_amd"))
+    from trex_gym.vec_env import TrexVecEnv
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rank, args=(2, port, ret), nprocs=2, join=True)
+    dev = torch.device("cuda", 0)
+    ref = TrexVecEnv(N_GLOBAL, urdf_path=ASSET_URDF, device=dev, max_episode_steps=4)
+    ref.reset_tensor()
+    ids = torch.arange(N_GLOBAL, device=dev)
+    rows = []
+    for t in range(STEPS):
+        ref.step_tensor(_actions(ref.model.lower, ref.model.upper, ids, t, dev))
+        rows.append(ref.rows.clone().cpu())
+    got = ret["got"]
+    assert got[0] is None
+    for t in range(1, STEPS + 1):                 # call t returns the rows of step t - 1, of BOTH shards
+        assert torch.equal(got[t], rows[t - 1]), t
+    assert torch.equal(ret["blocking"], rows[-1])
+    assert float(rows[3][:, 76].sum()) == N_GLOBAL     # the episode limit fired inside the launches, on every env
