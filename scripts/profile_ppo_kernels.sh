@@ -15,7 +15,9 @@ keep = [r for r in rows if any(k in r["Name"] for k in ("trex_step_kernel", "obs
 L = ["# PPO loop, per kernel (rocprofv3 --kernel-trace --stats; scripts/ppo_profile_workload.py: 4 rollouts x 32 steps + 32 minibatch steps, 4096 envs)", "",
      "| kernel | calls | avg us | total ms |", "|---|---|---|---|"]
 for r in keep:
-    L.append("| `%s` | %s | %.1f | %.2f |" % (r["Name"].split("(")[0][-60:], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
+    import re
+    name = re.search(r"(trex_step_kernel<[a-z, ]+>|trex_step_many_kernel|observe_kernel|act_kernel|learn_grad_kernel|learn_apply_kernel|gae_kernel|adv_stats_kernel|adam_kernel)", r["Name"]).group(1)
+    L.append("| `%s` | %s | %.1f | %.2f |" % (name, r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
 other = sum(float(r["TotalDurationNs"]) for r in rows if r not in keep) / 1e6
 L += ["", "everything else (PyTorch: noise, permutation, orthogonal initialisation ...): %.2f ms in total" % other]
 open(sys.argv[2], "w").write("\n".join(L) + "\n")
