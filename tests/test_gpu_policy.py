@@ -294,3 +294,52 @@ def test_native_minibatch_step_matches_the_oracle_and_autograd(mb):
     kern.minibatch_step(pol.theta, gbuf, m, vv, obs, act, logp0, val0, adv, ret, perm, first, mb, stats[2], cliprange=0.2,
                         ent_coef=0.01, vf_coef=0.5, lr=3e-4, eps=1e-5, max_grad_norm=0.5, loss_sums=sums)
     assert torch.isfinite(pol.theta).all() and float((pol.theta.cpu().double() - torch.tensor(want)).abs().max()) < 2.5 * 3e-4
+
+
+def test_policy_and_learner_kernels_at_other_dimensions():
+    """The kernels are written for MlpPolicy's hidden = 64 but any obs_dim <= 126 / act_dim <= 32 (the double pendulum
+    of tests/test_gpu_invariants.py has 6 / 2): act, GAE-free minibatch step and Adam against autograd + the oracle at
+    D = 6, A = 2; unsupported shapes are refused."""
+    from trex_gym import _capi
+    from trex_gym.ppo import MlpPolicy
+    torch.manual_seed(7)
+    D, A, n = 6, 2, 200
+    kern = _capi.Policy(n, D, A, 64, 0)
+    pol = MlpPolicy(kern.layout, kern.param_count, torch.device(DEV))
+    with torch.no_grad():
+        pol.theta.add_(0.1 * torch.randn_like(pol.theta))
+    rows = torch.randn(n, D + 2, device=DEV)
+    kern.set_stats(dict(obs_mean=np.zeros(D), obs_var=np.ones(D), obs_count=10.0, ret_mean=0.0, ret_var=1.0, ret_count=10.0))
+    noise = torch.randn(n, A, device=DEV)
+    actions, obs_n, logp, val = torch.empty(n, A, device=DEV), torch.empty(n, D, device=DEV), torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    kern.act(pol.theta, rows, noise, actions, obs_n, None, logp, val)
+    with torch.no_grad():
+        o = (rows[:, :D] / math.sqrt(1.0 + 1e-8)).clamp(-10, 10)
+        d = pol.dist(o)
+        a = d.loc + d.scale * noise
+        torch.testing.assert_close(actions, a, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(logp, d.log_prob(a).sum(-1), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(val, pol.value(o), rtol=1e-5, atol=1e-5)
+    # one native minibatch step against autograd
+    adv, ret, val0 = torch.randn(n, device=DEV), torch.randn(n, device=DEV), val + 0.2 * torch.randn(n, device=DEV)
+    logp0 = logp + 0.3 * torch.randn(n, device=DEV)
+    perm = torch.randperm(n, device=DEV)
+    stats = torch.zeros(1, 2, device=DEV)
+    kern.minibatch_stats(adv, perm, 1, n, stats)
+    a_n = (adv - adv.mean()) / (adv.std(unbiased=False) + 1e-8)
+    dd = pol.dist(obs_n)
+    ratio = (dd.log_prob(actions).sum(-1) - logp0).exp()
+    pg = torch.max(-a_n * ratio, -a_n * ratio.clamp(0.8, 1.2)).mean()
+    v = pol.value(obs_n)
+    vclip = val0 + (v - val0).clamp(-0.2, 0.2)
+    (pg + 0.5 * 0.5 * torch.max((v - ret) ** 2, (vclip - ret) ** 2).mean()).backward()
+    g_auto = pol.grad.detach().clone()
+    pol.grad.zero_()
+    gbuf, m, vv = torch.zeros_like(pol.theta), torch.zeros_like(pol.theta), torch.zeros_like(pol.theta)
+    kern.minibatch_step(pol.theta, gbuf, m, vv, obs_n, actions, logp0, val0, adv, ret, perm, 0, n, stats[0], loss_sums=None)
+    torch.testing.assert_close(gbuf, g_auto, rtol=1e-3, atol=1e-5 * float(g_auto.abs().max()))
+    assert torch.isfinite(pol.theta).all()
+    for bad in (dict(hidden=32), dict(act_dim=33), dict(obs_dim=127)):
+        kw = dict(num_envs=8, obs_dim=6, act_dim=2, hidden=64, device=0); kw.update(bad)
+        with pytest.raises(_capi.TrexError):
+            _capi.Policy(**kw)
