@@ -86,3 +86,23 @@ def test_reference_batch_size_and_a_long_horizon():
     assert float(long.b_done.sum()) >= 32 * 3          # three episode ends per env inside the horizon
     info = long.update((obs, act, logp, val, adv, ret, mean_rew))
     assert all(math.isfinite(v) for v in info.values()) and torch.isfinite(long.policy.theta).all()
+
+
+def test_play_records_mesh_poses_and_saved_weights_replay(tmp_path):
+    """train -> save -> play with export (the reference's play loop up to the renderer, trex_train.py:126-136) -> load
+    the file into a fresh agent (trex_train.py:75-110): same frames."""
+    import numpy as np
+    from trex_gym import trex_train
+    env = trex_train.build_environment(64, max_episode_steps=50)
+    ck = str(tmp_path / "policy.pt")
+    agent, _ = trex_train.train(env, num_timesteps=64 * 16 * 2, seed=0, nsteps=16, noptepochs=2, save_path=ck, log=lambda s: None)
+    frames, rew = trex_train.play(agent, 12, export_path=str(tmp_path / "rollout.npz"), log=lambda s: None)
+    z = np.load(str(tmp_path / "rollout.npz"))
+    assert z["poses"].shape == (12, 252, 7) and len(z["mesh_files"]) == 252 and z["mesh_files"][0].endswith(".obj")
+    assert np.isfinite(z["poses"]).all() and np.allclose(np.linalg.norm(z["poses"][..., 3:], axis=-1), 1.0, atol=1e-5)
+    assert float(np.abs(z["poses"][-1, :, :3] - z["poses"][0, :, :3]).max()) > 1e-3          # it moves
+    again = trex_train.load_agent(ck, num_envs=64, max_episode_steps=50)
+    assert torch.equal(again.policy.theta, agent.policy.theta)
+    f2, r2 = trex_train.play(again, 12, log=lambda s: None)
+    # (play() after load: the statistics restart from the saved ones and see the same observations: same frames)
+    assert np.allclose(f2[0], frames[0], atol=1e-6)

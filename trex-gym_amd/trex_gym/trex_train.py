@@ -4,7 +4,8 @@ vec env with the on-device PPO of trex_gym.ppo instead of baselines.ppo2 + TF1.
     python -m trex_gym.trex_train --num_timesteps 5000000 --num_envs 4096
 
 Reward weights are the training ones of the reference (distance 2e2, energy 1e-6, drift 1.0,
-trex_train.py:66). --play / --debug_render need pybullet's renderer and are out of scope.
+trex_train.py:66). --play runs the trained policy and records what a renderer needs per frame (the world poses of the 252
+visual meshes); drawing the frames (pybullet's renderer, --debug_render) is out of scope.
 """
 import argparse
 import os
@@ -18,7 +19,7 @@ from .vec_env import TrexVecEnv
 _URDF_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "assets", "trex_collide.urdf")
 
 
-def build_environment(num_envs, device="cuda:0", max_episode_steps=1000):
+def build_environment(num_envs, device="cuda:0", max_episode_steps=1000):   # (weights of trex_train.py:66)
     return TrexVecEnv(num_envs, urdf_path=_URDF_PATH, device=device, distance_weight=2e2, energy_weight=1e-6,
                       drift_weight=1.0, max_episode_steps=max_episode_steps)
 
@@ -46,9 +47,50 @@ def train(env, num_timesteps, seed, nsteps=32, noptepochs=None, save_path=None, 
     hist = agent.learn(num_timesteps, log=log)
     if save_path:
         st = agent.kern.get_stats()     # VecNormalize's running statistics travel with the weights (trex_train.py:93-99 restores both)
-        torch.save({"theta": agent.policy.theta, "layout": agent.kern.layout, "obs_mean": torch.tensor(st["obs_mean"]),
-                    "obs_var": torch.tensor(st["obs_var"]), "ret_var": float(st["ret_var"])}, save_path)
+        torch.save({"theta": agent.policy.theta.detach().clone(), "obs_mean": torch.tensor(st["obs_mean"]),
+                    "obs_var": torch.tensor(st["obs_var"]), "obs_count": torch.tensor(float(st["obs_count"])),
+                    "ret_var": torch.tensor(float(st["ret_var"]))}, save_path)
     return agent, hist
+
+
+def play(agent, num_play_timesteps, export_path=None, env_index=0, log=print):
+    """The reference's play loop (trex_train.py:126-136: model.step -> env.step -> render a frame -> PNGs -> ffmpeg) up to
+    the renderer: the trained policy drives the env with the MEAN action and every frame's world poses of the 252 visual
+    meshes are recorded (trex_batch_visual_transforms) - what a renderer needs to draw the frame; drawing itself is out
+    of scope. export_path: .npz with `mesh_files`, `mesh_links`, `poses` [T, 252, 7] (xyz + quaternion xyzw
+    of env `env_index`), `reward` [T], `fps` = 50 (metadata of trex_env.py:36)."""
+    import numpy as np
+    env, k = agent.env, agent.kern
+    zero = torch.zeros(env.num_envs, env.J, device=env.device)
+    frames, rewards = [], []
+    env.reset_tensor()
+    k.observe(env.rows, with_reward=False)
+    for _ in range(num_play_timesteps):
+        k.act(agent.policy.theta, env.rows, zero, agent.actions, clip_obs=agent.clip_obs)     # zero noise: the mean action
+        env.step_tensor(agent.actions)
+        frames.append(env.visual_transforms()[env_index].cpu().numpy())
+        rewards.append(float(env.rew[env_index]))
+    log("Episode reward: %.3f over %d frames" % (sum(rewards), len(rewards)))
+    if export_path:
+        table = env.model.visuals()
+        np.savez_compressed(export_path, mesh_files=np.array([t[0] for t in table]), mesh_links=np.array([t[1] for t in table]),
+                            poses=np.stack(frames).astype(np.float32), reward=np.array(rewards, np.float32), fps=np.float32(50.0))
+    return np.stack(frames), np.array(rewards)
+
+
+def load_agent(load_path, num_envs=1, device="cuda:0", max_episode_steps=1000):
+    """trex_train.py:75-110 (replay): rebuild the policy from a file written by train(save_path=...) - the flat
+    parameter vector and VecNormalize's statistics."""
+    ck = torch.load(load_path, map_location=device, weights_only=True)
+    env = build_environment(num_envs, device=device, max_episode_steps=max_episode_steps)
+    agent = PPO(env, nsteps=1, nminibatches=1, noptepochs=1)
+    with torch.no_grad():
+        agent.policy.theta.copy_(ck["theta"])
+    st = agent.kern.get_stats()
+    st.update(obs_mean=ck["obs_mean"].cpu().numpy(), obs_var=ck["obs_var"].cpu().numpy(), obs_count=float(ck["obs_count"]),
+              ret_var=float(ck["ret_var"]))
+    agent.kern.set_stats(st)
+    return agent
 
 
 def main(argv=None):
@@ -64,10 +106,15 @@ def main(argv=None):
     ap.add_argument("--max_episode_steps", type=int, default=1000)
     ap.add_argument("--save", type=str, default=None)
     ap.add_argument("--graphs", action="store_true", help="replay the rollout and the minibatch update as HIP graphs")
+    ap.add_argument("--play", action="store_true", help="after training: run the policy and record the frames' mesh poses (trex_train.py:25,126-136)")
+    ap.add_argument("--num_play_timesteps", type=int, default=int(2e3))          # trex_train.py:28
+    ap.add_argument("--export", type=str, default=None, help="with --play: .npz of mesh names + [T, 252, 7] world poses for an external renderer")
     args = ap.parse_args(argv)
     env = build_environment(args.num_envs, max_episode_steps=args.max_episode_steps)
-    train(env, args.num_timesteps, args.random_seed, args.nsteps, args.noptepochs, args.save, use_graphs=args.graphs,
-          preset=args.preset)
+    agent, _ = train(env, args.num_timesteps, args.random_seed, args.nsteps, args.noptepochs, args.save, use_graphs=args.graphs,
+                     preset=args.preset)
+    if args.play:
+        play(agent, args.num_play_timesteps, args.export)
 
 
 if __name__ == "__main__":
