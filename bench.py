@@ -346,13 +346,14 @@ def main():
             torch.cuda.synchronize()
 
     hist_bins = torch.arange(16, device=dev, dtype=torch.int32).unsqueeze(0)
+    # contact counts at both ends of the window: ONE tiny kernel each into buffers allocated HERE; the histogram arithmetic
+    # waits until after the timed region. (Rounds 2-3 built the first histogram with torch ops right before the warm-up:
+    # their fresh allocations - a [N, 16] mask, a reduction workspace - left the next ~25 launches 4-5 % slower, i.e.
+    # the whole 20-step window of the driver's call: 10.7 M with, 11.2 M without, three runs each.)
+    cnt_start = torch.zeros(n_local, dtype=torch.int32, device=dev)
+    cnt_end = torch.zeros(n_local, dtype=torch.int32, device=dev)
 
-    def contact_hist():
-        # stays on the device (read back after the timed region: no host round trip between pre-roll and warm-up)
-        # (and computed without torch.bincount, which reads the largest value back to size its output: a device-to-host
-        # wait of about a millisecond, after which the next ~40 launches run 3-7 % slower while the clocks come back)
-        cnt = torch.zeros(n_local, dtype=torch.int32, device=dev)
-        env.batch.contact_stats(cnt, None)
+    def contact_hist(cnt):
         return (cnt.clamp(0, 15).unsqueeze(1) == hist_bins).sum(0)
 
     env.reset_tensor()
@@ -361,25 +362,24 @@ def main():
     env.set_episode_steps(((ids * EPISODE_STEPS) // n_global).to(torch.int32))
     # The runtime frees the records of completed launches lazily, at the first launch AFTER a synchronize: with the
     # thousand pre-roll launches still on its books, the first TIMED launch (right after the mandatory fence) returned
-    # 0.15 - 0.6 ms late on the host (TREX_BENCH_DUMP_EVENTS=1 prints the enqueue times), the GPU idle meanwhile: six
-    # 20-step runs read 10.36 - 10.95 M. So the pre-roll synchronizes once, 100 steps before its end: the backlog at
-    # the fence is a hundred launches and the first timed launch is enqueued 0.02 ms after the clock starts
-    # (10.61 - 10.80 M over six runs: the same mean, a third of the spread). What remains of the gap to the 300-step
-    # line (11.17 M) is the GPU's: the ~40 launches that follow ANY synchronize run 3 - 4 % slower, and a 20-step
-    # window behind the mandatory fence consists of nothing else.
+    # 0.15 - 0.6 ms late on the host (TREX_BENCH_DUMP_EVENTS=1 prints the enqueue times), the GPU idle meanwhile. So the
+    # pre-roll synchronizes once, 100 steps before its end: the backlog at the fence is a hundred launches and the first
+    # timed launch is enqueued 0.02 ms after the clock starts. (Together with the histogram arithmetic moved out of the
+    # way - see cnt_start above - the driver's 20-step call reads 11.07 - 11.16 M over four runs; before: 10.4 - 10.95 M.)
     tail = min(100, args.preroll // 2)
     run(args.preroll - tail, 0)
     torch.cuda.synchronize()
     run(tail, args.preroll - tail)
     t_base = args.preroll
-    hist0 = contact_hist()   # (before the warm-up: nothing but the mandatory fence sits between warm-up and timing)
+    env.batch.contact_stats(cnt_start, None)   # (before the warm-up: nothing but the mandatory fence sits between warm-up and timing)
     run(args.warmup, t_base)
     fence()
     t0 = time.perf_counter()
     run(args.steps, t_base + args.warmup, timed=True)
     fence()
     dt = time.perf_counter() - t0
-    hist0, hist1 = ([int(x) for x in h.tolist()[:14]] for h in (hist0, contact_hist()))
+    env.batch.contact_stats(cnt_end, None)
+    hist0, hist1 = ([int(x) for x in contact_hist(c).tolist()[:14]] for c in (cnt_start, cnt_end))
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
