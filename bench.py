@@ -41,7 +41,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # (MI355X_MICROARCH.md, chip parameters + "v_fma_f32 (wave64) 2 cyc")
 VALU_ISSUE_PEAK_GIPS = 256 * 4 * 2.4 / 2.0   # 1228.8 G wave-instructions/s
 EPISODE_STEPS = 1000   # harness time limit (the reference never terminates, trex_env.py:183-184)
-EVENT_STRIDE = 4         # HIP-event pairs around every 4th launch of the timed region (see run())
+EVENT_STRIDE = 4         # N > 1: HIP-event pairs around every 4th launch of the timed region (see run()); one GPU: ONE spanning pair
 
 
 def _cpu_worker(args):
@@ -292,6 +292,8 @@ def main():
     stride = EVENT_STRIDE if args.steps >= EVENT_STRIDE else 1
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps // stride + 1)]
     sampled = []
+    span_events = world == 1 and not under_launcher and args.steps_per_launch == 1 and args.steps > 1
+    span = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     force_gather = under_launcher and world == 1 and bool(os.environ.get("TREX_BENCH_FORCE_GATHER"))
     pipe = (sharding.PipelinedGather(env.num_envs, env.rows.shape[1], 1, env.rows.dtype, dev) if force_gather else None)
     gather_mode = ["pipelined"]
@@ -320,7 +322,7 @@ def main():
             # HIP events (created before the clock starts) on the stream the kernel is launched on, around every
             # EVENT_STRIDE-th launch of the timed region: a timing event costs the stream about 4 us, two around EVERY
             # launch took 2.4 % off `value` (scripts/overlap_probe.py runs the same loop without events)
-            ev = events[t // stride] if (timed and t % stride == stride // 2) else None
+            ev = events[t // stride] if (timed and not span_events and t % stride == stride // 2) else None
             if ev:
                 ev[0].record()
             env.step_tensor(pool[(t_base + t) % n_draws])
@@ -329,6 +331,14 @@ def main():
             if ev:
                 ev[1].record()
                 sampled.append(ev)
+            if timed and span_events and n_steps > 1:
+                # one GPU: the stream carries nothing but back-to-back step launches, so ONE pair of HIP events spans the
+                # launches 2 .. K of the timed region (the first event sits behind launch 1: the host's start-up latency
+                # is not in it) and their average duration is the elapsed time / (K - 1): no event inside the region
+                if t == 0:
+                    span[0].record()
+                elif t == n_steps - 1:
+                    span[1].record()
             if world > 1:
                 if gather_mode[0] == "pipelined":
                     # overlaps the next step; a consumer sees the rows one step late and orders ITSELF behind the
@@ -365,7 +375,7 @@ def main():
     # 0.15 - 0.6 ms late on the host (TREX_BENCH_DUMP_EVENTS=1 prints the enqueue times), the GPU idle meanwhile. So the
     # pre-roll synchronizes once, 100 steps before its end: the backlog at the fence is a hundred launches and the first
     # timed launch is enqueued 0.02 ms after the clock starts. (Together with the histogram arithmetic moved out of the
-    # way - see cnt_start above - the driver's 20-step call reads 11.07 - 11.16 M over four runs; before: 10.4 - 10.95 M.)
+    # way - see cnt_start above - the driver's 20-step call reads 11.17 - 11.25 M over four runs; before: 10.4 - 10.95 M.)
     tail = min(100, args.preroll // 2)
     run(args.preroll - tail, 0)
     torch.cuda.synchronize()
@@ -402,14 +412,17 @@ def main():
         gather_mode[0] = "pipelined"
 
     # dominant kernel: average launch duration over the SAME timed region, from the HIP events
-    kernel_ms = sum(a.elapsed_time(b) for a, b in sampled) / len(sampled)
+    if span_events:
+        kernel_ms = span[0].elapsed_time(span[1]) / (args.steps - 1)
+    else:
+        kernel_ms = sum(a.elapsed_time(b) for a, b in sampled) / len(sampled)
     if S > 1:
         kernel_ms /= S        # per env-step: the figures below are per step of every env
     if host_times and rank == 0:
         print("host enqueue times of the timed steps [ms after t0]: " + " ".join("%.3f" % ((x - t0) * 1e3) for x in host_times)
               + " | window %.3f ms" % (dt * 1e3), file=sys.stderr)
     if os.environ.get("TREX_BENCH_DUMP_EVENTS") and rank == 0:   # per-launch durations of the timed region (diagnostic)
-        print("kernel ms per sampled timed step: " + " ".join("%.4f" % a.elapsed_time(b) for a, b in sampled), file=sys.stderr)
+        print("kernel ms per sampled timed step: " + (" ".join("%.4f" % a.elapsed_time(b) for a, b in sampled) or "(one span event pair)"), file=sys.stderr)
     finite = bool(torch.isfinite(many_rows if S > 1 else env.obs).all().item())
     info = env.batch.launch_info()
     build_id = _capi.build_id()
@@ -471,7 +484,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": "trex_step_many_kernel" if S > 1 else "trex_step_kernel<false, false>", "kernel_ms": kernel_ms,
                          "kernel_ms_covers": "one step launch = ONE kernel, trex_step_kernel<false, false> (it ranks the envs for the next launch and "
-                                             "resets the envs whose episode ends), bracketed by HIP events; every %d-th launch of the timed region is bracketed (%d samples)" % (stride, len(sampled)),
+                                             "resets the envs whose episode ends); " + ("ONE pair of HIP events spans launches 2 .. %d of the timed region (back-to-back on the stream): elapsed / %d" % (args.steps, args.steps - 1)
+                                                                                     if span_events else "every %d-th launch of the timed region is bracketed by HIP events (%d samples)" % (stride, len(sampled))),
                          "alg_bytes_per_launch": alg, "kernel_build": build_id,
                          "note": "latency/VALU-bound by construction (serial PGS); HBM fraction reported as "
                                  "BASELINE asks, roofline_issue is the bound that matters (DESIGN.md)"},
