@@ -16,7 +16,7 @@ L = ["# PPO loop, per kernel (rocprofv3 --kernel-trace --stats; scripts/ppo_prof
      "| kernel | calls | avg us | total ms |", "|---|---|---|---|"]
 for r in keep:
     import re
-    name = re.search(r"(trex_step_kernel<[a-z, ]+>|trex_step_many_kernel|observe_kernel|act_kernel|learn_grad_kernel|learn_apply_kernel|gae_kernel|adv_stats_kernel|adam_kernel)", r["Name"]).group(1)
+    name = re.search(r"(trex_step_kernel<[a-z, ]+>|trex_step_many_kernel|observe_kernel|act_kernel|learn_grad_kernel|learn_reduce_kernel|learn_adam_kernel|learn_apply_kernel|gae_kernel|adv_stats_kernel|adam_kernel)", r["Name"]).group(1)
     L.append("| `%s` | %s | %.1f | %.2f |" % (name, r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
 other = sum(float(r["TotalDurationNs"]) for r in rows if r not in keep) / 1e6
 L += ["", "everything else (PyTorch: noise, permutation, orthogonal initialisation ...): %.2f ms in total" % other]

@@ -1,4 +1,4 @@
-// PPO2 minibatch step as two launches (include/trex_policy.h: trex_policy_minibatch_step).
+// PPO2 minibatch step as three launches (include/trex_policy.h: trex_policy_minibatch_step).
 //
 // What baselines' ppo2 Model.train does per minibatch through TensorFlow (trex_train.py:49-61: forward of both
 // MLPs, clipped surrogate + clipped value loss, backward, global-norm clip, Adam) costs a stock autograd framework ~90
@@ -13,9 +13,10 @@
 //                       the MFMA's k dimension, so the activation tile and the delta tile make ONE trip through a
 //                       private LDS buffer of the wave, written [row][env] and read back with the env as k). Every
 //                       tile writes its gradient contribution to its own slice of a partial buffer: no atomics.
-//   learn_apply_kernel  sums the per-tile partials IN TILE ORDER (deterministic), adds the entropy term, and the last
-//                       workgroup to end takes the global norm (in workgroup order), clips and applies Adam in
-//                       TensorFlow's form to the flat parameter vector.
+//   learn_reduce_kernel sums the per-tile partials IN TILE ORDER (deterministic), adds the entropy term, writes the gradient
+//                       and each workgroup's squared norm;
+//   learn_adam_kernel   takes the global norm (workgroup order), clips and applies Adam in TensorFlow's form to the flat
+//                       parameter vector, 256 float4s per workgroup.
 //
 // The arithmetic is the one restated in f64 by oracle/ppo_oracle.py::ppo_loss_and_grads / clip_by_global_norm / Adam.
 #include <hip/hip_runtime.h>
@@ -84,12 +85,13 @@ __device__ __forceinline__ void copy_rows(float *dst, const float *src, int rows
   if (((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (cols & 3) == 0) {
     const float4 *s4 = reinterpret_cast<const float4 *>(src);
     const int n4 = n >> 2;
-    for (int i0 = tid; i0 < n4; i0 += nthreads * 8) {
-      float4 t[8];
+    constexpr int UF = 16;     // loads in flight per thread and trip (nothing else is live while the parameters are staged)
+    for (int i0 = tid; i0 < n4; i0 += nthreads * UF) {
+      float4 t[UF];
 #pragma unroll
-      for (int u = 0; u < 8; u++) { const int i = i0 + nthreads * u; t[u] = s4[i < n4 ? i : 0]; }
+      for (int u = 0; u < UF; u++) { const int i = i0 + nthreads * u; t[u] = s4[i < n4 ? i : 0]; }
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
+      for (int u = 0; u < UF; u++) {
         const int i = i0 + nthreads * u;
         if (i < n4) {
           const int e = 4 * i, r = e / cols;
@@ -100,12 +102,12 @@ __device__ __forceinline__ void copy_rows(float *dst, const float *src, int rows
     }
     return;
   }
-  for (int i0 = tid; i0 < n; i0 += nthreads * 8) {
-    float t[8];
+  for (int i0 = tid; i0 < n; i0 += nthreads * 16) {
+    float t[16];
 #pragma unroll
-    for (int u = 0; u < 8; u++) { const int i = i0 + nthreads * u; t[u] = src[i < n ? i : 0]; }
+    for (int u = 0; u < 16; u++) { const int i = i0 + nthreads * u; t[u] = src[i < n ? i : 0]; }
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < 16; u++) {
       const int i = i0 + nthreads * u;
       if (i < n) { const int r = i / cols; dst[r * dst_stride + (i - r * cols)] = t[u]; }
     }
@@ -132,20 +134,27 @@ __global__ __launch_bounds__(128) void learn_grad_kernel(LearnArgs g) {
   const int s0 = blockIdx.x * TILE;                       // first sample of the tile within the minibatch
   float *X = lds + L.X;
   constexpr int XC = 96;                                  // columns of X that the weight-gradient tiles read (3 x 32)
-  for (int idx0 = tid; idx0 < TILE * XC; idx0 += 128 * 4) {
-    float raw[4];
-    int ii[4], kk[4];
+  {
+    // the tile's sample indices: ONE trip (they used to be fetched in front of every observation load: two dependent
+    // trips per batch of four loads, twelve in all)
+    __shared__ long long tile_rows[TILE];
+    if (tid < TILE) tile_rows[tid] = s0 + tid < g.mb ? g.perm[g.first + s0 + tid] : -1;
+    __syncthreads();
+    constexpr int UX = 12;                                // TILE * XC / 128 = 24 elements per thread: two trips
+    for (int idx0 = tid; idx0 < TILE * XC; idx0 += 128 * UX) {
+      float raw[UX];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int idx = idx0 + 128 * u;
-      ii[u] = idx / XC; kk[u] = idx - ii[u] * XC;
-      const bool ok = idx < TILE * XC && kk[u] < D && s0 + ii[u] < g.mb;
-      const long long row = ok ? g.perm[g.first + s0 + ii[u]] : 0;
-      raw[u] = ok ? g.obs[(size_t)row * D + kk[u]] : 0.f;
+      for (int u = 0; u < UX; u++) {
+        const int idx = idx0 + 128 * u, ii = idx / XC, kk = idx - ii * XC;
+        const long long row = tile_rows[ii];
+        raw[u] = (kk < D && row >= 0) ? g.obs[(size_t)row * D + kk] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < UX; u++) {
+        const int idx = idx0 + 128 * u, ii = idx / XC, kk = idx - ii * XC;
+        X[ii * XS + kk] = raw[u];
+      }
     }
-#pragma unroll
-    for (int u = 0; u < 4; u++)
-      if (idx0 + 128 * u < TILE * XC) X[ii[u] * XS + kk[u]] = raw[u];
   }
   __syncthreads();
   const int col = lane & 31, h = lane >> 5;
@@ -434,16 +443,19 @@ struct ApplyArgs {
   float ent_coef, lr, b1, b2, eps, max_norm, inv_mb;
 };
 
-constexpr int AP_COLS = 64, AP_GROUPS = 4;
-__global__ __launch_bounds__(AP_COLS * AP_GROUPS) void learn_apply_kernel(ApplyArgs g) {
+// Two launches (no last-workgroup serial tail: a single workgroup updating 21 k parameters in six dependent trips
+// behind two device-scope fences was most of the old single launch's 31 us):
+//   learn_reduce_kernel  one float4 column of the partial rows per thread, 8 tile groups per workgroup (two trips of 8
+//                        loads), groups added in order -> grad, + the workgroup's squared norm; workgroup 0 advances
+//                        the Adam step count
+//   learn_adam_kernel    every workgroup sums the squared norms (workgroup order), clips and updates its 256 float4s
+constexpr int AP_COLS = 64, AP_GROUPS = 8;
+__global__ __launch_bounds__(AP_COLS * AP_GROUPS) void learn_reduce_kernel(ApplyArgs g) {
   __shared__ float4 part[AP_GROUPS][AP_COLS];
   __shared__ double wred[AP_COLS * AP_GROUPS / 64];
-  __shared__ bool last;
-  __shared__ float lr_sh, scale_sh;
   const int tid = threadIdx.x, c = tid & (AP_COLS - 1), grp = tid / AP_COLS;
   const int n4 = g.stride >> 2;                         // float4 columns of a partial row (the last one: the loss sums)
   const int c4 = blockIdx.x * AP_COLS + c;
-  // ---- group q sums the tiles q, q + 4, ... in order (8 loads in flight), then group 0 adds the four in order
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c4 < n4) {
     const float4 *P = reinterpret_cast<const float4 *>(g.partial) + c4;
@@ -472,8 +484,11 @@ __global__ __launch_bounds__(AP_COLS * AP_GROUPS) void learn_apply_kernel(ApplyA
         if (i >= g.count) e[k] = 0.f;
         else if (i >= g.logstd_off && i < g.logstd_off + g.A) e[k] -= g.ent_coef;      // d(-ent_coef * entropy)/dlogstd
         sq += (double)e[k] * e[k];
-        if (i < g.count) g.grad[i] = e[k];
       }
+      if (4 * c4 + 3 < g.count) reinterpret_cast<float4 *>(g.grad)[c4] = make_float4(e[0], e[1], e[2], e[3]);
+      else
+        for (int k = 0; k < 4; k++)
+          if (4 * c4 + k < g.count) g.grad[4 * c4 + k] = e[k];
     }
   }
   for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
@@ -483,57 +498,47 @@ __global__ __launch_bounds__(AP_COLS * AP_GROUPS) void learn_apply_kernel(ApplyA
     double t = 0.0;
     for (int w = 0; w < AP_COLS * AP_GROUPS / 64; w++) t += wred[w];
     g.red[blockIdx.x] = t;
+    if (blockIdx.x == 0) *g.step = *g.step + 1;        // (read by the Adam launch that follows on the stream)
   }
-  // ---- the last workgroup to end: global norm (workgroup order), clip, Adam on the whole vector
-  __threadfence();
+}
+
+__global__ __launch_bounds__(256) void learn_adam_kernel(ApplyArgs g, int reduce_groups) {
+  __shared__ double rsh[256];
+  __shared__ float lr_sh, scale_sh;
+  const int tid = threadIdx.x;
+  rsh[tid] = tid < reduce_groups ? g.red[tid] : 0.0;
   __syncthreads();
-  if (tid == 0) last = atomicAdd(g.counter, 1u) == gridDim.x - 1;
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
   if (tid == 0) {
     double t = 0.0;
-    for (unsigned w = 0; w < gridDim.x; w++) t += g.red[w];
+    for (int w = 0; w < reduce_groups && w < 256; w++) t += rsh[w];       // workgroup order: the same sum in every workgroup
+    for (int w = 256; w < reduce_groups; w++) t += g.red[w];
     const float norm = (float)sqrt(t);
     scale_sh = g.max_norm > 0.f ? g.max_norm / fmaxf(norm, g.max_norm) : 1.f;        // tf.clip_by_global_norm
-    const int st = *g.step + 1;
+    const int st = *g.step;
     lr_sh = (float)((double)g.lr * sqrt(1.0 - pow((double)g.b2, (double)st)) / (1.0 - pow((double)g.b1, (double)st)));
-    *g.step = st;
-    *g.counter = 0u;
   }
   __syncthreads();
   const float scale = scale_sh, lr_t = lr_sh;
-  const int P4 = g.count >> 2;
-  float4 *t4 = reinterpret_cast<float4 *>(g.theta), *m4 = reinterpret_cast<float4 *>(g.m), *v4 = reinterpret_cast<float4 *>(g.v);
-  const float4 *g4 = reinterpret_cast<const float4 *>(g.grad);
   auto upd = [&](float gr, float &mi, float &vi, float &th) {
     const float gi = gr * scale;
     mi = g.b1 * mi + (1.f - g.b1) * gi;
     vi = g.b2 * vi + (1.f - g.b2) * gi * gi;
     th -= lr_t * mi / (sqrtf(vi) + g.eps);
   };
-  for (int i0 = tid; i0 < P4; i0 += 256 * 4) {
-    float4 gv[4], tv[4], mv[4], vv[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int i = i0 + 256 * u;
-      if (i < P4) { gv[u] = g4[i]; tv[u] = t4[i]; mv[u] = m4[i]; vv[u] = v4[i]; }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int i = i0 + 256 * u;
-      if (i < P4) {
-        upd(gv[u].x, mv[u].x, vv[u].x, tv[u].x); upd(gv[u].y, mv[u].y, vv[u].y, tv[u].y);
-        upd(gv[u].z, mv[u].z, vv[u].z, tv[u].z); upd(gv[u].w, mv[u].w, vv[u].w, tv[u].w);
-        t4[i] = tv[u]; m4[i] = mv[u]; v4[i] = vv[u];
-      }
-    }
+  const int i = blockIdx.x * 256 + tid, P4 = g.count >> 2;
+  if (i < P4) {
+    float4 *t4 = reinterpret_cast<float4 *>(g.theta), *m4 = reinterpret_cast<float4 *>(g.m), *v4 = reinterpret_cast<float4 *>(g.v);
+    const float4 gv = reinterpret_cast<const float4 *>(g.grad)[i];
+    float4 tv = t4[i], mv = m4[i], vv = v4[i];
+    upd(gv.x, mv.x, vv.x, tv.x); upd(gv.y, mv.y, vv.y, tv.y); upd(gv.z, mv.z, vv.z, tv.z); upd(gv.w, mv.w, vv.w, tv.w);
+    t4[i] = tv; m4[i] = mv; v4[i] = vv;
   }
-  for (int i = (P4 << 2) + tid; i < g.count; i += 256) {
-    float mi = g.m[i], vi = g.v[i], th = g.theta[i];
-    upd(g.grad[i], mi, vi, th);
-    g.m[i] = mi; g.v[i] = vi; g.theta[i] = th;
-  }
+  if (blockIdx.x == 0)
+    for (int k = (P4 << 2) + tid; k < g.count; k += 256) {
+      float mi = g.m[k], vi = g.v[k], th = g.theta[k];
+      upd(g.grad[k], mi, vi, th);
+      g.m[k] = mi; g.v[k] = vi; g.theta[k] = th;
+    }
 }
 
 }  // namespace
@@ -602,7 +607,9 @@ int trex_policy_minibatch_step(TrexPolicy *p, float *theta_dev, float *grad_dev,
   HIP_TRY(hipGetLastError());
   ApplyArgs b{p->grad_partial, theta_dev, grad_dev, m_dev, v_dev, loss_sums_dev, p->learn_red, p->learn_counter, p->adam_step,
               tiles, stride, p->lay.count, p->lay.logstd, p->A, ent_coef, lr, beta1, beta2, eps, max_grad_norm, 1.0f / (float)mb};
-  hipLaunchKernelGGL(learn_apply_kernel, dim3(apply_groups), dim3(AP_COLS * AP_GROUPS), 0, (hipStream_t)stream, b);
+  hipLaunchKernelGGL(learn_reduce_kernel, dim3(apply_groups), dim3(AP_COLS * AP_GROUPS), 0, (hipStream_t)stream, b);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(learn_adam_kernel, dim3(((p->lay.count >> 2) + 255) / 256), dim3(256), 0, (hipStream_t)stream, b, apply_groups);
   HIP_TRY(hipGetLastError());
   return TREX_OK;
 }
