@@ -33,22 +33,27 @@ constexpr int W2S = HID + 1;           // LDS row stride of W2 (transposed reads
 constexpr int XS = MAXD + 1;           // LDS row stride of the observation tile
 constexpr int TS = TILE + 1;           // LDS row stride of the [row][env] transposition buffers
 
-struct LdsLayout {   // offsets (floats) of the LDS copy of theta, W2 padded to W2S. Block of net k starts at k * vf; inside a
-  //                    block: W1 at 0, then b1, W2, b2, W3, b3 (scalar fields only: an array indexed by the net would live in scratch)
-  int vf, b1, W2, b2, W3, logstd, X, buf, total;
-  __host__ __device__ int base(int net) const { return net ? vf : 0; }
+// The LDS copy of theta MIRRORS the global layout (policy_common.h: every block on a multiple of 4 floats) except that the
+// rows of the two W2 matrices are padded to W2S words: a global float at offset i sits at i + shift(i), where the shift
+// grows by HID after each W2 (its 64 pad words) and, inside a W2, by one per row. One flat loop stages everything.
+struct LdsLayout {
+  int X, buf, total;           // observation tile; per-wave transposition buffers; floats in all
 };
-__host__ __device__ inline LdsLayout make_lds_layout(int D, int A) {
+__host__ __device__ inline LdsLayout make_lds_layout(const Layout &lay) {
   LdsLayout l{};
-  l.b1 = D * HID; l.W2 = l.b1 + HID; l.b2 = l.W2 + HID * W2S; l.W3 = l.b2 + HID;
-  l.vf = l.W3 + HID * A + A;                       // the policy block: W3 [H, A], b3 [A]
-  int o = l.vf + l.W3 + HID + 1;                   // the value block: W3 [H, 1], b3 [1]
-  l.logstd = o; o += A;
+  int o = lay.count + 2 * HID;                         // theta + the pad words of the two W2s
   o = (o + 3) & ~3;
   l.X = o; o += TILE * XS;
   l.buf = o; o += 2 * 2 * HID * TS;      // per wave: ACT [64][TS] + DEL [64][TS]
   l.total = o;
   return l;
+}
+// LDS offset of the global parameter at offset i (i a multiple of 4 for the float4 path: a float4 never crosses a W2 row)
+__device__ __forceinline__ int lds_of(const Layout &lay, int i) {
+  int o = i;
+  if (i >= lay.pW2) o += (i < lay.pb2) ? (i - lay.pW2) / HID : HID;
+  if (i >= lay.vW2) o += (i < lay.vb2) ? (i - lay.vW2) / HID : HID;
+  return o;
 }
 
 struct LearnArgs {
@@ -77,60 +82,30 @@ __device__ __forceinline__ float half_sum(float v) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-__device__ __forceinline__ void copy_rows(float *dst, const float *src, int rows, int cols, int dst_stride, int tid, int nthreads) {
-  // [rows][cols] -> [rows][dst_stride]. 16-byte loads where the source allows it (offsets into theta are multiples of 4
-  // floats for every weight matrix of a 75/64/25 policy; checked at run time), 8 loads in flight per thread and trip:
-  // with 4-byte loads the 21 k parameters took every thread 21 dependent round trips to L2
-  const int n = rows * cols;
-  if (((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (cols & 3) == 0) {
-    const float4 *s4 = reinterpret_cast<const float4 *>(src);
-    const int n4 = n >> 2;
-    constexpr int UF = 16;     // loads in flight per thread and trip (nothing else is live while the parameters are staged)
-    for (int i0 = tid; i0 < n4; i0 += nthreads * UF) {
-      float4 t[UF];
-#pragma unroll
-      for (int u = 0; u < UF; u++) { const int i = i0 + nthreads * u; t[u] = s4[i < n4 ? i : 0]; }
-#pragma unroll
-      for (int u = 0; u < UF; u++) {
-        const int i = i0 + nthreads * u;
-        if (i < n4) {
-          const int e = 4 * i, r = e / cols;
-          float *d = dst + r * dst_stride + (e - r * cols);       // (a float4 never crosses a row: cols % 4 == 0)
-          d[0] = t[u].x; d[1] = t[u].y; d[2] = t[u].z; d[3] = t[u].w;
-        }
-      }
-    }
-    return;
-  }
-  for (int i0 = tid; i0 < n; i0 += nthreads * 16) {
-    float t[16];
-#pragma unroll
-    for (int u = 0; u < 16; u++) { const int i = i0 + nthreads * u; t[u] = src[i < n ? i : 0]; }
-#pragma unroll
-    for (int u = 0; u < 16; u++) {
-      const int i = i0 + nthreads * u;
-      if (i < n) { const int r = i / cols; dst[r * dst_stride + (i - r * cols)] = t[u]; }
-    }
-  }
-}
-
 __global__ __launch_bounds__(128) void learn_grad_kernel(LearnArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, net = tid >> 6;     // wave 0: policy net, wave 1: value net
   const int D = g.lay.D, A = g.lay.A;
-  const LdsLayout L = make_lds_layout(D, A);
-  // ---- stage the parameters (W2 with padded rows) and the tile's observations
+  const LdsLayout L = make_lds_layout(g.lay);
+  // ---- stage the parameters: one flat loop of 16-byte loads, 16 in flight per thread (three trips for 21 k floats)
   {
-    const float *th = g.theta;
-    float *P0 = lds, *P1 = lds + L.vf;
-    copy_rows(P0, th + g.lay.pW1, D, HID, HID, tid, 128);            copy_rows(P1, th + g.lay.vW1, D, HID, HID, tid, 128);
-    copy_rows(P0 + L.b1, th + g.lay.pb1, 1, HID, HID, tid, 128);     copy_rows(P1 + L.b1, th + g.lay.vb1, 1, HID, HID, tid, 128);
-    copy_rows(P0 + L.W2, th + g.lay.pW2, HID, HID, W2S, tid, 128);   copy_rows(P1 + L.W2, th + g.lay.vW2, HID, HID, W2S, tid, 128);
-    copy_rows(P0 + L.b2, th + g.lay.pb2, 1, HID, HID, tid, 128);     copy_rows(P1 + L.b2, th + g.lay.vb2, 1, HID, HID, tid, 128);
-    copy_rows(P0 + L.W3, th + g.lay.pW3, HID, A, A, tid, 128);       copy_rows(P1 + L.W3, th + g.lay.vW3, HID, 1, 1, tid, 128);
-    copy_rows(P0 + L.W3 + HID * A, th + g.lay.pb3, 1, A, A, tid, 128); copy_rows(P1 + L.W3 + HID, th + g.lay.vb3, 1, 1, 1, tid, 128);
+    const float4 *s4 = reinterpret_cast<const float4 *>(g.theta);
+    const int n4 = g.lay.count >> 2;                    // (count is a multiple of 4: policy_common.h)
+    constexpr int UF = 16;
+    for (int i0 = tid; i0 < n4; i0 += 128 * UF) {
+      float4 t[UF];
+#pragma unroll
+      for (int u = 0; u < UF; u++) { const int i = i0 + 128 * u; t[u] = s4[i < n4 ? i : 0]; }
+#pragma unroll
+      for (int u = 0; u < UF; u++) {
+        const int i = i0 + 128 * u;
+        if (i < n4) {
+          float *d = lds + lds_of(g.lay, 4 * i);
+          d[0] = t[u].x; d[1] = t[u].y; d[2] = t[u].z; d[3] = t[u].w;
+        }
+      }
+    }
   }
-  copy_rows(lds + L.logstd, g.theta + g.lay.logstd, 1, A, A, tid, 128);
   const int s0 = blockIdx.x * TILE;                       // first sample of the tile within the minibatch
   float *X = lds + L.X;
   constexpr int XC = 96;                                  // columns of X that the weight-gradient tiles read (3 x 32)
@@ -160,9 +135,26 @@ __global__ __launch_bounds__(128) void learn_grad_kernel(LearnArgs g) {
   const int col = lane & 31, h = lane >> 5;
   const bool valid = s0 + col < g.mb;
   const long long sidx = valid ? g.perm[g.first + s0 + col] : 0;
-  const float *PB = lds + L.base(net);
-  const float *W1 = PB, *b1 = PB + L.b1, *W2 = PB + L.W2, *b2 = PB + L.b2;
-  const float *W3 = PB + L.W3, *b3 = PB + L.W3 + HID * (net ? 1 : A);
+  // the sample's loss inputs, fetched NOW: their round trips hide behind the forward pass (read where the loss needs
+  // them they cost the kernel 3 us)
+  f32x16 act_in;
+  float adv_in = 0.f, logp0_in = 0.f, val0_in = 0.f, ret_in = 0.f, advm = 0.f, advr = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; r++) act_in[r] = 0.f;
+  if (net == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int a = rowmap(r, h);
+      if (a < A && valid) act_in[r] = g.act[(size_t)sidx * A + a];
+    }
+    if (valid) { adv_in = g.adv[sidx]; logp0_in = g.logp0[sidx]; }
+    advm = g.adv_stats[0]; advr = g.adv_stats[1];
+  } else if (valid) {
+    val0_in = g.val0[sidx]; ret_in = g.ret[sidx];
+  }
+  const float *W1 = lds + lds_of(g.lay, net ? g.lay.vW1 : g.lay.pW1), *b1 = lds + lds_of(g.lay, net ? g.lay.vb1 : g.lay.pb1);
+  const float *W2 = lds + lds_of(g.lay, net ? g.lay.vW2 : g.lay.pW2), *b2 = lds + lds_of(g.lay, net ? g.lay.vb2 : g.lay.pb2);
+  const float *W3 = lds + lds_of(g.lay, net ? g.lay.vW3 : g.lay.pW3), *b3 = lds + lds_of(g.lay, net ? g.lay.vb3 : g.lay.pb3);
   float *ACT = lds + L.buf + net * 2 * HID * TS, *DEL = ACT + HID * TS;
   float *out = g.partial + (size_t)blockIdx.x * g.stride;
   const float inv_mb = 1.0f / (float)g.mb;
@@ -220,7 +212,7 @@ __global__ __launch_bounds__(128) void learn_grad_kernel(LearnArgs g) {
         mu = __builtin_amdgcn_mfma_f32_32x32x2f32(col < A ? W3[k * A + col] : 0.f, h2[t][s], mu, 0, 0, 0);
       }
     }
-    const float *ls = lds + L.logstd;
+    const float *ls = lds + lds_of(g.lay, g.lay.logstd);
     f32x16 z, isd;
     float zz = 0.f, sum_ls = 0.f;
 #pragma unroll
@@ -231,7 +223,7 @@ __global__ __launch_bounds__(128) void learn_grad_kernel(LearnArgs g) {
         const float l = ls[a];
         sum_ls += l;
         isd[r] = expf(-l);
-        const float ac = valid ? g.act[(size_t)sidx * A + a] : mu[r];
+        const float ac = valid ? act_in[r] : mu[r];
         z[r] = (ac - mu[r]) * isd[r];
         zz = __builtin_fmaf(z[r], z[r], zz);
       }
@@ -239,8 +231,8 @@ __global__ __launch_bounds__(128) void learn_grad_kernel(LearnArgs g) {
     zz += __shfl_xor(zz, 32, 64);
     sum_ls += __shfl_xor(sum_ls, 32, 64);
     const float logp = -0.5f * zz - sum_ls - 0.5f * LOG_2PI * (float)A;
-    const float an = valid ? (g.adv[sidx] - g.adv_stats[0]) * g.adv_stats[1] : 0.f;
-    const float ratio = valid ? expf(logp - g.logp0[sidx]) : 1.f;
+    const float an = valid ? (adv_in - advm) * advr : 0.f;
+    const float ratio = valid ? expf(logp - logp0_in) : 1.f;
     const float rc = fminf(fmaxf(ratio, 1.f - g.cliprange), 1.f + g.cliprange);
     const float l1 = -an * ratio, l2 = -an * rc;
     const bool through = l1 >= l2 || rc == ratio;      // the branch of max() that carries a gradient w.r.t. ratio
@@ -306,7 +298,7 @@ __global__ __launch_bounds__(128) void learn_grad_kernel(LearnArgs g) {
     }
     v += __shfl_xor(v, 32, 64);
     v += b3[0];
-    const float v0 = valid ? g.val0[sidx] : v, rt = valid ? g.ret[sidx] : v;
+    const float v0 = valid ? val0_in : v, rt = valid ? ret_in : v;
     const float dvc = fminf(fmaxf(v - v0, -g.cliprange), g.cliprange);
     const float vclip = v0 + dvc;
     const float e1 = (v - rt) * (v - rt), e2 = (vclip - rt) * (vclip - rt);
@@ -600,7 +592,7 @@ int trex_policy_minibatch_step(TrexPolicy *p, float *theta_dev, float *grad_dev,
       p->allocs.push_back(p->learn_red);
     }
   }
-  const LdsLayout L = make_lds_layout(p->D, p->A);
+  const LdsLayout L = make_lds_layout(p->lay);
   LearnArgs a{theta_dev, obs_dev, act_dev, logp_dev, val_dev, adv_dev, ret_dev, reinterpret_cast<const long long *>(perm_dev),
               adv_stats_dev, p->grad_partial, first, mb, stride, cliprange, vf_coef, p->lay};
   hipLaunchKernelGGL(learn_grad_kernel, dim3(tiles), dim3(128), (size_t)L.total * sizeof(float), (hipStream_t)stream, a);
