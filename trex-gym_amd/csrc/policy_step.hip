@@ -85,27 +85,28 @@ __global__ __launch_bounds__(256) void act_kernel(ActArgs g) {
   float *th = lds;                                       // [count] parameters
   float *Xall = lds + ((g.lay.count + 3) & ~3);          // [ACT_TILES][TILE][MAXD + 1] normalised observations (+ zero pad)
   {
-    // (8 loads per thread in flight per trip: left as a plain loop, every 16-byte load waited for its own round trip)
+    // (11 loads per thread in flight per trip: left as a plain loop, every 16-byte load waited for its own round trip)
     const float4 *src = reinterpret_cast<const float4 *>(g.theta);
     float4 *dst = reinterpret_cast<float4 *>(th);
     const int n4 = g.lay.count >> 2;
-    for (int i0 = tid; i0 < n4; i0 += 256 * 8) {
-      float4 t[8];
+    for (int i0 = tid; i0 < n4; i0 += 256 * 11) {     // 21 float4 per thread: two trips of 11
+      float4 t[11];
 #pragma unroll
-      for (int u = 0; u < 8; u++) { const int i = i0 + 256 * u; t[u] = src[i < n4 ? i : 0]; }
+      for (int u = 0; u < 11; u++) { const int i = i0 + 256 * u; t[u] = src[i < n4 ? i : 0]; }
 #pragma unroll
-      for (int u = 0; u < 8; u++) { const int i = i0 + 256 * u; if (i < n4) dst[i] = t[u]; }
+      for (int u = 0; u < 11; u++) { const int i = i0 + 256 * u; if (i < n4) dst[i] = t[u]; }
     }
     for (int i = (n4 << 2) + tid; i < g.lay.count; i += 256) th[i] = g.theta[i];
   }
   // ---- stage the tiles: normalise, clip, keep a copy for the rollout buffer
   const int eb = blockIdx.x * (ACT_TILES * TILE);
-  for (int idx0 = tid; idx0 < ACT_TILES * TILE * Dp; idx0 += 256 * 4) {
-    float raw[4], mean[4], rstd[4];
-    int ii[4], kk[4];
-    bool ok[4];
+  constexpr int UX = 10;      // 19 elements per thread at D = 75: two trips
+  for (int idx0 = tid; idx0 < ACT_TILES * TILE * Dp; idx0 += 256 * UX) {
+    float raw[UX], mean[UX], rstd[UX];
+    int ii[UX], kk[UX];
+    bool ok[UX];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < UX; u++) {
       const int idx = idx0 + 256 * u;
       ii[u] = idx / Dp; kk[u] = idx - ii[u] * Dp;
       ok[u] = idx < ACT_TILES * TILE * Dp && kk[u] < D && eb + ii[u] < g.n;
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void act_kernel(ActArgs g) {
       mean[u] = g.norm[kc]; rstd[u] = g.norm[D + kc];
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < UX; u++) {
       if (idx0 + 256 * u >= ACT_TILES * TILE * Dp) continue;
       float x = 0.f;
       if (ok[u]) {
@@ -131,6 +132,14 @@ __global__ __launch_bounds__(256) void act_kernel(ActArgs g) {
   const int col = lane & 31, h = lane >> 5;
   const float *W1 = th + (net ? g.lay.vW1 : g.lay.pW1), *b1 = th + (net ? g.lay.vb1 : g.lay.pb1);
   const float *W2 = th + (net ? g.lay.vW2 : g.lay.pW2), *b2 = th + (net ? g.lay.vb2 : g.lay.pb2);
+  // the sample's noise draws, fetched now: their round trip hides behind the MFMA phases
+  const int e = e0 + col;
+  f32x16 nz_in;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int a = rowmap(r, h);
+    nz_in[r] = (net == 0 && !g.value_only && a < A && e < g.n) ? g.noise[(size_t)e * A + a] : 0.f;
+  }
   // ---- layer 1: h1^T = tanh(W1^T x^T + b1); B operand = the observation of env `col` from LDS
   f32x16 h1[2], h2[2];
 #pragma unroll
@@ -156,7 +165,6 @@ __global__ __launch_bounds__(256) void act_kernel(ActArgs g) {
   }
   // ---- layer 2, activations from registers
   hidden_layer(W2, b2, h1, h2, col, h);
-  const int e = e0 + col;
   if (net == 1) {
     // ---- value head: one output; every lane sums its 32 neurons, the two halves of an env meet by a swap
     const float *w = th + g.lay.vW3;
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(256) void act_kernel(ActArgs g) {
       const float l = ls[a], sd = expf(l);
       sum_ls += l;
       if (e < g.n) {
-        const float nz = g.noise[(size_t)e * A + a];
+        const float nz = nz_in[r];
         const float act = __builtin_fmaf(sd, nz, mu[r]);
         const float z = (act - mu[r]) / sd;            // as the learner recomputes it from the stored action
         zz = __builtin_fmaf(z, z, zz);
@@ -233,13 +241,13 @@ __global__ __launch_bounds__(128 * OBS_GROUPS) void observe_kernel(ObserveArgs g
   // Sums are taken about the RUNNING mean (a shift that every workgroup knows): no cancellation in the variance.
   double s = 0.0, ss = 0.0, sr = 0.0;
   if (c < D) {
-    const double shift = g.stats[c];
-    for (int r = r0; r < r1; r += 8) {
-      float x[8];
+    for (int r = r0; r < r1; r += 16) {       // 16 rows per row group: ONE trip
+      float x[16];
 #pragma unroll
-      for (int u = 0; u < 8; u++) x[u] = r + u < r1 ? g.rows[(size_t)(r + u) * g.row_stride + c] : 0.f;
+      for (int u = 0; u < 16; u++) x[u] = r + u < r1 ? g.rows[(size_t)(r + u) * g.row_stride + c] : 0.f;
+      const double shift = g.stats[c];          // (behind the row loads: one round trip for both)
 #pragma unroll
-      for (int u = 0; u < 8; u++)
+      for (int u = 0; u < 16; u++)
         if (r + u < r1) { const double d = (double)x[u] - shift; s += d; ss += d * d; }
     }
   } else if (c == D && g.with_reward) {
