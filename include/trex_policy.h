@@ -84,7 +84,7 @@ int trex_policy_adam(TrexPolicy *policy, float *theta_dev, float *grad_dev, floa
                      float beta1, float beta2, float eps, float max_grad_norm, float *grad_norm_out, void *stream);
 int trex_policy_adam_reset(TrexPolicy *policy, void *stream);
 
-/* ---- the learner: one PPO2 minibatch step (ppo2's Model.train, trex_train.py:49-61) as two launches ----
+/* ---- the learner: one PPO2 minibatch step (ppo2's Model.train, trex_train.py:49-61) as three launches ----
  * The rollout buffers are flat [num_samples, ...] f32 device arrays (num_samples = T x N): obs (NORMALISED, as the
  * policy saw them), act, logp (log-probability under the rollout policy), val (its value estimates), adv, ret.
  * perm_dev [>= first + mb] i64 device: a permutation of the sample indices (an epoch's shuffle); the minibatch is

@@ -497,7 +497,7 @@ class Policy:
     def minibatch_step(self, theta, grad, m, v, obs, act, logp, val, adv, ret, perm, first, mb, adv_stats, cliprange=0.2,
                        ent_coef=0.0, vf_coef=0.5, lr=3e-4, beta1=0.9, beta2=0.999, eps=1e-5, max_grad_norm=0.5, loss_sums=None,
                        stream=None):
-        """One PPO2 minibatch step on perm[first : first + mb] (include/trex_policy.h): two launches."""
+        """One PPO2 minibatch step on perm[first : first + mb] (include/trex_policy.h): three launches."""
         P, N, D, A = self.param_count, adv.numel(), self.D, self.A
         check(lib.trex_policy_minibatch_step(
             self.h, self._p(theta, P, "theta"), self._p(grad, P, "grad"), self._p(m, P, "m"), self._p(v, P, "v"),

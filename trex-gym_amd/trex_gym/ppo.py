@@ -69,8 +69,8 @@ class PPO:
     def __init__(self, env, nsteps=32, nminibatches=32, noptepochs=4, gamma=0.99, lam=0.95, lr=3e-4,
                  cliprange=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, clip_obs=10.0, clip_rew=10.0,
                  seed=0, use_graphs=False, native_learner=True):
-        """native_learner: the minibatch step is two HIP launches (trex_policy_minibatch_step: forward + analytic
-        backward on the matrix cores, then partial sums -> clip -> Adam) instead of ~90 autograd kernels; False keeps
+        """native_learner: the minibatch step is three HIP launches (trex_policy_minibatch_step: forward + analytic
+        backward on the matrix cores, then ordered partial sums, then clip + Adam) instead of ~90 autograd kernels; False keeps
         the PyTorch autograd path (the f32 reference the native step is tested against).
         use_graphs: capture the whole nsteps rollout (policy kernel + env step + statistics kernel per step) and
         one epoch of minibatch updates as HIP graphs and replay them - everything launched is stream-ordered, so it
