@@ -365,6 +365,24 @@ def test_bad_tensors_are_refused(full, capi):
     v.batch.step(a, obs, rew, done)                           # and the well-formed call still works
 
 
+def test_validated_allocations_are_cached_by_range_and_can_be_forgotten():
+    """The C-ABI validates every caller ALLOCATION once: any pointer into a validated allocation with enough room behind
+    it passes (a [T, n, 25] action pool presents a new pointer every step), a pointer with too little room behind it is
+    refused, and trex_batch_forget_buffers() drops the cache (for callers that free buffers they have passed)."""
+    n = 64
+    v = make_vec(n)
+    v.reset_tensor()
+    pool = torch.zeros(5, n, 25, device=DEV)
+    for t in range(5):
+        v.step_tensor(pool[t])                              # five different pointers, one allocation
+    tail = pool.reshape(-1)[-(n * 25 - 8):]                 # starts 8 floats late: too short for [n, 25]
+    with pytest.raises(Exception):
+        v.batch.step_rows(tail, v.rows, v.penalties, done=v.done)
+    v.batch.forget_buffers()
+    o1, r1, _ = v.step_tensor(pool[0])                      # validated afresh
+    assert torch.isfinite(o1).all() and torch.isfinite(r1).all()
+
+
 def test_full_clipping_equals_clipped_actions(full):
     v, lo, hi = full
     g = torch.Generator(device=DEV).manual_seed(2)
