@@ -141,7 +141,9 @@ int trex_batch_step(TrexBatch *batch, const float *actions_dev, float *obs_dev, 
 
 /* The same two calls writing ONE row block (what the multi-GPU exchange gathers):
  *   rows_dev [N, row_stride] f32 device, row_stride >= 3J + 2:
- *     [0, 3J) observation, [3J] reward, [3J+1] done as 0.0 / 1.0; columns beyond 3J+2 are not touched.
+ *     [0, 3J) observation, [3J] reward, [3J+1] done as 0.0 / 1.0; and, when row_stride >= 3J + 5, [3J+2, 3J+5) the
+ *     three penalties (lifting_com, station_keeping, energy: trex_env.py:193-195) - one message for a consumer
+ *     that wants them. Columns beyond are not touched.
  * done_dev [N] u8, nullable: the done flags once more as bytes (what a consumer masks with - saves it a
  *   conversion pass over the column). trex_batch_reset_rows writes the observation columns of every env (reset or
  *   not) and, for the envs it resets, reward = 0 and done = 0: the row of a new episode. */

@@ -173,16 +173,16 @@ def test_step_is_graph_capturable_and_stream_ordered():
     graph = TrexVecEnv(n, urdf_path=ASSET_URDF, device=DEV)
     eager.reset_tensor(); graph.reset_tensor()
     torch.cuda.synchronize()
-    graph.batch.step_rows(a, graph.rows, graph.penalties)   # (first call validates the buffers; not captured)
-    eager.batch.step_rows(a, eager.rows, eager.penalties)
+    graph.batch.step_rows(a, graph.rows)   # (first call validates the buffers; not captured)
+    eager.batch.step_rows(a, eager.rows)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):            # captures on a side stream; _capi passes torch's current stream down
-        graph.batch.step_rows(a, graph.rows, graph.penalties)
+        graph.batch.step_rows(a, graph.rows)
     for t in range(12):
         a.copy_(0.3 * torch.sin(torch.arange(25, device=DEV) + t).expand(n, 25))
         g.replay()
-        eager.batch.step_rows(a, eager.rows, eager.penalties)
+        eager.batch.step_rows(a, eager.rows)
     torch.cuda.synchronize()
     assert (graph.rows == eager.rows).all() and (graph.penalties == eager.penalties).all()
     assert (graph.get_state() == eager.get_state()).all()

@@ -377,7 +377,7 @@ def test_validated_allocations_are_cached_by_range_and_can_be_forgotten():
         v.step_tensor(pool[t])                              # five different pointers, one allocation
     tail = pool.reshape(-1)[-(n * 25 - 8):]                 # starts 8 floats late: too short for [n, 25]
     with pytest.raises(Exception):
-        v.batch.step_rows(tail, v.rows, v.penalties, done=v.done)
+        v.batch.step_rows(tail, v.rows, None, done=v.done)
     v.batch.forget_buffers()
     o1, r1, _ = v.step_tensor(pool[0])                      # validated afresh
     assert torch.isfinite(o1).all() and torch.isfinite(r1).all()
@@ -439,6 +439,26 @@ def test_reset_with_the_done_flags_of_the_last_step():
         v.reset_tensor(torch.zeros(6, dtype=torch.int32, device=DEV))  # neither uint8 nor bool
 
 
+def test_row_block_of_77_and_of_80_columns():
+    """trex_batch_step_rows: a [n, 3J+2] row block (obs | reward | done) with the penalties in an array of their own ==
+    the [n, 3J+5] block that carries them behind done (what TrexVecEnv allocates: whole 32-byte sectors per env)."""
+    n = 50
+    g = torch.Generator(device=DEV).manual_seed(31)
+    a = (torch.rand(n, 25, device=DEV, generator=g) - 0.5).contiguous()
+    wide, narrow = make_vec(n, penalties_in_rows=True), make_vec(n)
+    wide.reset_tensor(); narrow.reset_tensor()
+    rows77, pen = torch.zeros(n, 77, device=DEV), torch.zeros(n, 3, device=DEV)
+    for _ in range(35):
+        wide.step_tensor(a)
+        narrow.batch.step_rows(a, rows77, pen)
+    assert wide.rows.shape == (n, 80)
+    assert torch.equal(wide.rows[:, :77], rows77) and torch.equal(wide.penalties, pen)
+    assert float(pen.abs().sum()) > 0
+    mask = torch.zeros(n, dtype=torch.uint8, device=DEV); mask[3] = 1
+    wide.reset_tensor(mask)                                    # a reset zeroes the row's reward / done / penalty columns
+    assert float(wide.rows[3, 75:80].abs().sum()) == 0.0 and float(wide.rows[4, 77:80].abs().sum()) > 0.0
+
+
 def test_wave_balance_setting_is_a_batch_property():
     """trex_batch_set_wave_balance: -1 auto (on from 2048 envs), 0 off, 1 on. Results are bitwise independent of it -
     also when it is forced on below the automatic threshold and when it is switched while the batch is running."""
@@ -496,15 +516,16 @@ def test_step_many_is_bitwise_the_same_steps_one_by_one(model):
         a.step_tensor(acts[s_])
         rows_a.append(a.rows.clone()); pen_a.append(a.penalties.clone()); done_a.append(a.done.clone())
     b = prepare()
-    rows_b = torch.empty(S, n, 77, device=DEV)
+    rows_b = torch.empty(S, n, 80, device=DEV)          # obs | reward | done | 3 penalties (the wide form of the row block)
     pen_b = torch.empty(S, n, 3, device=DEV)
     done_b = torch.zeros(S, n, dtype=torch.bool, device=DEV)
     b.batch.step_many(acts, rows_b, pen_b, done_b)
     assert bool(done_b[0, 17]) and float(rows_b[0, 17, 75]) == 0.0       # containment inside the launch
     assert int(done_b.sum()) > S * n // 9 - n                              # episodes ended in every step
     for s_ in range(S):
-        assert torch.equal(rows_b[s_], rows_a[s_]), s_
+        assert torch.equal(rows_b[s_, :, :77], rows_a[s_]), s_
         assert torch.equal(pen_b[s_], pen_a[s_]) and torch.equal(done_b[s_], done_a[s_]), s_
+        assert torch.equal(rows_b[s_, :, 77:80], pen_b[s_])             # the penalties ride in the row block, too
     assert torch.equal(b.get_state(), a.get_state())
     assert torch.equal(b.episode_steps, a.episode_steps)
     ca, cb = torch.zeros(n, dtype=torch.int32, device=DEV), torch.zeros(n, dtype=torch.int32, device=DEV)
@@ -517,7 +538,7 @@ def test_step_many_is_bitwise_the_same_steps_one_by_one(model):
     assert torch.equal(oa, ob) and torch.equal(ra, rb)
     # the convenience wrapper
     rows_c = prepare().step_many_tensor(acts)
-    assert torch.equal(rows_c, rows_b)
+    assert torch.equal(rows_c, rows_b[:, :, :77])
     with pytest.raises(Exception):
         b.batch.step_many(acts, rows_b[:, :100])                           # rows of the wrong shape are refused
 

@@ -16,9 +16,9 @@
 
 extern "C" {
 hipError_t trex_launch_step(const TrexDeviceModel *, TrexBatchArrays, int, const float *, float *, float *, uint8_t *,
-                            float *, float, float, float, float *, hipStream_t, float *, int, int, int);
+                            float *, float, float, float, float *, hipStream_t, float *, int, int, int, int);
 hipError_t trex_launch_reset(const TrexDeviceModel *, TrexBatchArrays, int, const uint8_t *, float *, float, float,
-                             float, float *, hipStream_t, int, float *, float *, int);
+                             float, float *, hipStream_t, int, float *, float *, int, int);
 hipError_t trex_launch_step_many(const TrexDeviceModel *, TrexBatchArrays, int, const float *, float *, int, int, float *, uint8_t *,
                                  float, float, float, hipStream_t, int, int);
 hipError_t trex_launch_pack_state(const TrexDeviceModel *, TrexBatchArrays, int, float *, int, hipStream_t);
@@ -498,7 +498,7 @@ int trex_batch_reset(TrexBatch *b, const uint8_t *mask_dev, float *obs_out_dev, 
   BUF_TRY(mask_dev, n, "trex_batch_reset: mask");
   BUF_TRY(obs_out_dev, n * 3 * b->nj * sizeof(float), "trex_batch_reset: obs_out");
   HIP_TRY(trex_launch_reset(b->dmodel, b->arr, b->n, mask_dev, obs_out_dev, b->wd, b->we, b->wk, nullptr,
-                            (hipStream_t)stream, 3 * b->nj, nullptr, nullptr, 1));
+                            (hipStream_t)stream, 3 * b->nj, nullptr, nullptr, 1, b->nj));
   return TREX_OK;
 }
 
@@ -509,9 +509,9 @@ int trex_batch_reset_rows(TrexBatch *b, const uint8_t *mask_dev, float *rows_dev
   DeviceGuard guard(b->device);
   const size_t n = (size_t)b->n;
   BUF_TRY(mask_dev, n, "trex_batch_reset_rows: mask");
-  BUF_TRY(rows_dev, ((n - 1) * row_stride + 3 * b->nj + 2) * sizeof(float), "trex_batch_reset_rows: rows");
+  BUF_TRY(rows_dev, ((n - 1) * row_stride + 3 * b->nj + (row_stride >= 3 * b->nj + 5 ? 5 : 2)) * sizeof(float), "trex_batch_reset_rows: rows");
   HIP_TRY(trex_launch_reset(b->dmodel, b->arr, b->n, mask_dev, rows_dev, b->wd, b->we, b->wk, nullptr,
-                            (hipStream_t)stream, row_stride, rows_dev + 3 * b->nj, rows_dev + 3 * b->nj + 1, row_stride));
+                            (hipStream_t)stream, row_stride, rows_dev + 3 * b->nj, rows_dev + 3 * b->nj + 1, row_stride, b->nj));
   return TREX_OK;
 }
 
@@ -527,7 +527,7 @@ int trex_batch_step(TrexBatch *b, const float *actions_dev, float *obs_dev, floa
   BUF_TRY(done_dev, n, "trex_batch_step: done");
   BUF_TRY(penalties_dev, n * 3 * sizeof(float), "trex_batch_step: penalties");
   HIP_TRY(trex_launch_step(b->dmodel, b->arr, b->n, actions_dev, obs_dev, reward_dev, done_dev, penalties_dev, b->wd,
-                           b->we, b->wk, nullptr, (hipStream_t)stream, nullptr, 3 * b->nj, 1, b->balance()));
+                           b->we, b->wk, nullptr, (hipStream_t)stream, nullptr, 3 * b->nj, 1, b->balance(), 0));
   return TREX_OK;
 }
 
@@ -539,12 +539,12 @@ int trex_batch_step_rows(TrexBatch *b, const float *actions_dev, float *rows_dev
   DeviceGuard guard(b->device);
   const size_t n = (size_t)b->n;
   BUF_TRY(actions_dev, n * b->nj * sizeof(float), "trex_batch_step_rows: actions");
-  BUF_TRY(rows_dev, ((n - 1) * row_stride + 3 * b->nj + 2) * sizeof(float), "trex_batch_step_rows: rows");
+  BUF_TRY(rows_dev, ((n - 1) * row_stride + 3 * b->nj + (row_stride >= 3 * b->nj + 5 ? 5 : 2)) * sizeof(float), "trex_batch_step_rows: rows");
   BUF_TRY(penalties_dev, n * 3 * sizeof(float), "trex_batch_step_rows: penalties");
   BUF_TRY(done_dev, n, "trex_batch_step_rows: done");
   float *rew = rows_dev + 3 * b->nj;
   HIP_TRY(trex_launch_step(b->dmodel, b->arr, b->n, actions_dev, rows_dev, rew, done_dev, penalties_dev, b->wd, b->we,
-                           b->wk, nullptr, (hipStream_t)stream, rew + 1, row_stride, row_stride, b->balance()));
+                           b->wk, nullptr, (hipStream_t)stream, rew + 1, row_stride, row_stride, b->balance(), row_stride >= 3 * b->nj + 5));
   return TREX_OK;
 }
 
@@ -557,7 +557,7 @@ int trex_batch_step_many(TrexBatch *b, const float *actions_dev, float *rows_dev
   DeviceGuard guard(b->device);
   const size_t n = (size_t)b->n, S = (size_t)num_steps;
   BUF_TRY(actions_dev, S * n * b->nj * sizeof(float), "trex_batch_step_many: actions");
-  BUF_TRY(rows_dev, ((S * n - 1) * row_stride + 3 * b->nj + 2) * sizeof(float), "trex_batch_step_many: rows");
+  BUF_TRY(rows_dev, ((S * n - 1) * row_stride + 3 * b->nj + (row_stride >= 3 * b->nj + 5 ? 5 : 2)) * sizeof(float), "trex_batch_step_many: rows");
   BUF_TRY(penalties_dev, S * n * 3 * sizeof(float), "trex_batch_step_many: penalties");
   BUF_TRY(done_dev, S * n, "trex_batch_step_many: done");
   HIP_TRY(trex_launch_step_many(b->dmodel, b->arr, b->n, actions_dev, rows_dev, row_stride, num_steps, penalties_dev, done_dev,
@@ -573,7 +573,7 @@ int trex_batch_debug_step(TrexBatch *b, const float *actions_dev, float *obs_dev
   BUF_TRY(obs_dev, (size_t)b->n * 3 * b->nj * sizeof(float), "trex_batch_debug_step: obs");
   BUF_TRY(debug_dev, 4096 * sizeof(float), "trex_batch_debug_step: debug");   // (diagnostic builds: 4096 + 16 N)
   HIP_TRY(trex_launch_step(b->dmodel, b->arr, b->n, actions_dev, obs_dev, nullptr, nullptr, nullptr, b->wd, b->we, b->wk,
-                           debug_dev, (hipStream_t)stream, nullptr, 3 * b->nj, 1, b->balance()));
+                           debug_dev, (hipStream_t)stream, nullptr, 3 * b->nj, 1, b->balance(), 0));
   return TREX_OK;
 }
 
@@ -714,7 +714,7 @@ int trex_batch_time_steps(TrexBatch *b, const float *actions_dev, float *obs_dev
   HIP_TRY(hipEventRecord(e0, s));
   for (int i = 0; i < steps; i++)
     HIP_TRY(trex_launch_step(b->dmodel, b->arr, b->n, actions_dev, obs_dev, reward_dev, done_dev, nullptr, b->wd, b->we,
-                             b->wk, nullptr, s, nullptr, 3 * b->nj, 1, b->balance()));
+                             b->wk, nullptr, s, nullptr, 3 * b->nj, 1, b->balance(), 0));
   HIP_TRY(hipEventRecord(e1, s));
   HIP_TRY(hipEventSynchronize(e1));
   float ms = 0.f;

@@ -363,6 +363,7 @@ struct KernelArgs {
   // row block at + s * step_rows floats (obs, reward, done_f alike), done bytes at + s * N, penalties at + s * 3 N
   int n_steps;
   long long step_rows;
+  int pen_in_rows;        // row-block launches with row_stride >= 3J + 5: the three penalties follow done in the row
 };
 
 }  // namespace
@@ -1942,6 +1943,11 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
         float *pn = args.penalties + ((size_t)(MULTI ? ls : 0) * args.n_envs + env) * 3;
         pn[0] = env_bad ? 0.f : lift; pn[1] = env_bad ? 0.f : drift; pn[2] = env_bad ? 0.f : energy;
       }
+      if (args.pen_in_rows) {     // ... obs | reward | done | lifting, station keeping, energy: one aligned 320-byte row at J = 25
+        float *pn = args.done_f + so + (size_t)env * args.scal_stride + 1;
+        const bool zero = RESET || env_bad;
+        pn[0] = zero ? 0.f : lift; pn[1] = zero ? 0.f : drift; pn[2] = zero ? 0.f : energy;
+      }
     }
   }
   steps_in = steps_out;
@@ -2165,11 +2171,12 @@ extern "C" {
 hipError_t trex_launch_step(const TrexDeviceModel *model, TrexBatchArrays arr, int n, const float *actions,
                             float *obs, float *reward, uint8_t *done, float *penalties, float wd, float we,
                             float wk, float *debug, hipStream_t stream, float *done_f, int obs_stride, int scal_stride,
-                            int balance) {
+                            int balance, int pen_in_rows) {
   // balance: the env-to-wave assignment by contact rank (trex_batch_set_wave_balance decides; capi.cpp). Diagnostics
   // launches keep env k in workgroup k (the stamped build is balanced like the product: it reports the env of every wave)
   int32_t *perm = ((debug && !TREX_STAMPS) || !balance) ? nullptr : arr.balance;
-  KernelArgs a{model, arr, n, actions, obs, reward, done, done_f, obs_stride, scal_stride, penalties, nullptr, perm, wd, we, wk, debug};
+  KernelArgs a{model, arr, n, actions, obs, reward, done, done_f, obs_stride, scal_stride, penalties, nullptr, perm, wd, we, wk, debug,
+               1, 0, pen_in_rows};
 #if TREX_STAMPS   // diagnostic build: the PRODUCT instantiation, stamped (the dump of <false, true> would change its code)
   hipLaunchKernelGGL((trex_step_kernel<false, false>), dim3(n), dim3(64), 0, stream, a);
 #else
@@ -2186,15 +2193,16 @@ hipError_t trex_launch_step_many(const TrexDeviceModel *model, TrexBatchArrays a
                                  hipStream_t stream, int balance, int nj) {
   float *rew = rows + 3 * nj;
   KernelArgs a{model, arr, n, actions, rows, rew, done, rew + 1, row_stride, row_stride, penalties, nullptr,
-               balance ? arr.balance : nullptr, wd, we, wk, nullptr, n_steps, (long long)n * row_stride};
+               balance ? arr.balance : nullptr, wd, we, wk, nullptr, n_steps, (long long)n * row_stride, row_stride >= 3 * nj + 5};
   hipLaunchKernelGGL(trex_step_many_kernel, dim3(n), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
 
 hipError_t trex_launch_reset(const TrexDeviceModel *model, TrexBatchArrays arr, int n, const uint8_t *mask,
                              float *obs, float wd, float we, float wk, float *debug, hipStream_t stream, int obs_stride,
-                             float *reward, float *done_f, int scal_stride) {
-  KernelArgs a{model, arr, n, nullptr, obs, reward, nullptr, done_f, obs_stride, scal_stride, nullptr, mask, nullptr, wd, we, wk, debug};
+                             float *reward, float *done_f, int scal_stride, int nj) {
+  KernelArgs a{model, arr, n, nullptr, obs, reward, nullptr, done_f, obs_stride, scal_stride, nullptr, mask, nullptr, wd, we, wk, debug,
+               1, 0, (reward && done_f && obs_stride >= 3 * nj + 5) ? 1 : 0};
   hipLaunchKernelGGL((trex_step_kernel<true, false>), dim3(n), dim3(64), 0, stream, a);
   return hipGetLastError();
 }

@@ -322,7 +322,7 @@ class Batch:
         if done is not None and done.dtype not in (torch.uint8, torch.bool):
             raise TrexError(E_INVALID, "done: expected dtype uint8 or bool, got %s" % done.dtype)
         check(lib.trex_batch_step_rows(self.h, self._p(actions, "float32", n * J, "actions"),
-                                       self._p(rows, "float32", n * (3 * J + 2), "rows"), int(rows.shape[1]),
+                                       self._p(rows, "float32", (n - 1) * rows.shape[1] + 3 * J + (5 if rows.shape[1] >= 3 * J + 5 else 2), "rows"), int(rows.shape[1]),
                                        self._p(penalties, "float32", 3 * n, "penalties"),
                                        _ptr(done, self.device, None, n, "done"), self._stream(stream)))
 
@@ -335,15 +335,15 @@ class Batch:
         if rows.dim() != 3 or int(rows.shape[0]) != S or int(rows.shape[1]) != n:
             raise TrexError(E_INVALID, "rows: expected shape [%d, %d, >= %d], got %s" % (S, n, 3 * J + 2, tuple(rows.shape)))
         check(lib.trex_batch_step_many(self.h, self._p(actions, "float32", S * n * J, "actions"),
-                                       self._p(rows, "float32", (S * n - 1) * rows.shape[2] + 3 * J + 2, "rows"), int(rows.shape[2]), S,
+                                       self._p(rows, "float32", (S * n - 1) * rows.shape[2] + 3 * J + (5 if rows.shape[2] >= 3 * J + 5 else 2), "rows"), int(rows.shape[2]), S,
                                        self._p(penalties, "float32", 3 * S * n, "penalties"), _ptr(done, self.device, None, S * n, "done"),
                                        self._stream(stream)))
 
     def reset_rows(self, rows, mask=None, stream=None):
         n, J = self.num_envs, self.J
         check(lib.trex_batch_reset_rows(self.h, self._mask(mask),
-                                        self._p(rows, "float32", n * (3 * J + 2), "rows"), int(rows.shape[1]),
-                                        self._stream(stream)))
+                                        self._p(rows, "float32", (n - 1) * rows.shape[1] + 3 * J + (5 if rows.shape[1] >= 3 * J + 5 else 2), "rows"),
+                                        int(rows.shape[1]), self._stream(stream)))
 
     def set_episode_limit(self, max_episode_steps, episode_steps=None, stream=None):
         """Episode limit inside the step launch (0 = off); episode_steps [n] int32 sets the per-env counts."""

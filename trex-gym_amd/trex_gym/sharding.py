@@ -51,9 +51,10 @@ def pack_rows(obs, reward, done, out=None):
     return out
 
 
-def split_rows(rows):
-    """[N, 3J+2] row block -> (obs [N, 3J], reward [N], done [N] bool) views."""
-    c = rows.shape[1] - 2
+def split_rows(rows, obs_cols=None):
+    """[N, 3J+2] row block -> (obs [N, 3J], reward [N], done [N] bool) views. obs_cols = 3J for wider rows (the
+    GPU env's 3J+5 form also carries the three penalties behind done: rows[:, 3J+2:3J+5])."""
+    c = rows.shape[1] - 2 if obs_cols is None else int(obs_cols)
     return rows[:, :c], rows[:, c], rows[:, c + 1] != 0
 
 

@@ -9,8 +9,9 @@ step_async(), step_wait(), step(), close(); plus tensor-native variants that kee
 harness's: `max_episode_steps` (None = never) auto-resets like a VecEnv does and reports done=True -
 inside the step launch itself (trex_batch_set_episode_limit).
 
-Outputs live in ONE row block `rows` [n, 3J+2] f32 = obs | reward | done (written by the kernel in that
-layout: trex_batch_step_rows); `obs`, `rew` and `done_f` are views into it; `done` holds the flags as bool.
+Outputs live in ONE row block `rows` [n, 3J+2] f32 = obs | reward | done (written by the kernel in that layout:
+trex_batch_step_rows; with penalties_in_rows [n, 3J+5]: the three penalties behind done); `obs`, `rew`, `done_f` are views
+into it; `done` holds the flags as bool, `penalties` [n, 3] the three reward terms.
 
 Multi-GPU: one process per GPU, env ids sharded by contiguous range (trex_gym.sharding); the only
 exchange is the all-gather of that row block (all_gather_rows / all_gather_rows_pipelined).
@@ -29,7 +30,8 @@ class TrexVecEnv(spaces.Env):       # gym.Env where gym is importable; the surfa
     def __init__(self, num_envs, urdf_path=None, collisions_dir=None, device=None, action_repeat=1,
                  distance_weight=1.0, energy_weight=0.005, drift_weight=0.002,
                  max_episode_steps=None, starting_configuration=None, params=None,
-                 rank=0, world_size=1, process_group=None, collision="hulls", primitive_max_radius=0.2, row_buffers=1):
+                 rank=0, world_size=1, process_group=None, collision="hulls", primitive_max_radius=0.2, row_buffers=1,
+                 penalties_in_rows=False):
         """num_envs is the GLOBAL env count; this process owns sharding.shard_range(num_envs, rank, world_size).
         row_buffers=2: successive steps write two row blocks in turn (`rows`, `obs`, `rew`, `done_f` always name the
         block of the LAST step), which lets the pipelined all-gather read a block in place."""
@@ -66,11 +68,15 @@ class TrexVecEnv(spaces.Env):       # gym.Env where gym is importable; the surfa
         n = self.num_envs
         # obs | reward | done. row_buffers=2: the steps write two blocks in turn, so that a block can be gathered in
         # place while the next step runs (all_gather_rows_pipelined without a staging copy)
-        self._row_blocks = [torch.zeros(n, 3 * J + 2, device=self.device) for _ in range(int(row_buffers))]
+        # penalties_in_rows: [n, 3J+5] rows that carry the three penalties behind done (one message for a consumer that
+        # wants them); default [n, 3J+2] + a `penalties` tensor of its own. (The 80-column form was MEASURED to cost
+        # more HBM write traffic, not less - 8.1 against 3.7 MB per launch of 4096 envs, PMC WRITE_SIZE: DESIGN.md 6.)
+        self._pen_in_rows = bool(penalties_in_rows)
+        self._row_blocks = [torch.zeros(n, 3 * J + (5 if self._pen_in_rows else 2), device=self.device) for _ in range(int(row_buffers))]
+        self._penalties = None if self._pen_in_rows else torch.zeros(n, 3, device=self.device)
         self._row_k = 0
         self._point_at(0)
         self.done = torch.zeros(n, dtype=torch.bool, device=self.device)   # the same flags as bytes (written by the kernel too)
-        self.penalties = torch.zeros(n, 3, device=self.device)
         self.max_episode_steps = max_episode_steps
         if max_episode_steps is not None:
             # the step launch itself resets an env whose episode is over (no reset launch between two steps)
@@ -112,7 +118,7 @@ class TrexVecEnv(spaces.Env):       # gym.Env where gym is importable; the surfa
         # reward of the finished step, observation of the new episode - VecEnv semantics, no second launch)
         if len(self._row_blocks) > 1:
             self._point_at(1 - self._row_k)
-        self.batch.step_rows(actions, self.rows, self.penalties, done=self.done)
+        self.batch.step_rows(actions, self.rows, self._penalties, done=self.done)   # (None: the penalties ride in the row block)
         return self.obs, self.rew, self.done
 
     def step_many_tensor(self, actions, rows=None):
@@ -125,7 +131,7 @@ class TrexVecEnv(spaces.Env):       # gym.Env where gym is importable; the surfa
             raise ValueError("actions must have shape (S, %d, %d), got %s" % (self.num_envs, self.J, tuple(actions.shape)))
         S = int(actions.shape[0])
         if rows is None:
-            rows = torch.empty(S, self.num_envs, 3 * self.J + 2, device=self.device)
+            rows = torch.empty(S, self.num_envs, self.rows.shape[1], device=self.device)
         self.batch.step_many(actions, rows)
         self.rows.copy_(rows[-1])
         self.done.copy_(self.done_f != 0)
@@ -136,10 +142,12 @@ class TrexVecEnv(spaces.Env):       # gym.Env where gym is importable; the surfa
         self._row_k = k
         self.rows = self._row_blocks[k]
         self.obs, self.rew, self.done_f = self.rows[:, :3 * J], self.rows[:, 3 * J], self.rows[:, 3 * J + 1]
+        # lifting_com, station_keeping, energy (trex_env.py:193-195)
+        self.penalties = self.rows[:, 3 * J + 2:3 * J + 5] if self._pen_in_rows else self._penalties
 
     def all_gather_rows(self, rows=None):
         """[global N, 3J+2] = obs | reward | done of EVERY env, on every rank: the one collective of the path
-        (RCCL all-gather over xGMI; gloo in the CPU tests). sharding.split_rows() cuts it back into the three."""
+        (RCCL all-gather over xGMI; gloo in the CPU tests). sharding.split_rows(rows, 3 * J) cuts it back."""
         rows = self.rows if rows is None else rows
         if self.world_size == 1:
             return rows
