@@ -97,7 +97,8 @@ int trex_policy_adam_reset(TrexPolicy *policy, void *stream);
  *   TensorFlow's form (lr, beta1, beta2, eps) on theta / m / v [P]; the step count is the policy object's
  *   (trex_policy_adam_reset). grad_dev [P]: receives the UNclipped gradient of this minibatch (scratch; tests read it).
  *   adv_stats_dev [2]: this minibatch's row of the stats above. loss_sums_dev [2] f32 device, nullable: the
- *   minibatch's mean surrogate loss and mean value loss are ADDED to it (zero it per update; divide by the steps). */
+ *   minibatch's mean surrogate loss and mean value loss are ADDED to it (zero it per update; divide by the steps).
+ *   obs_dim <= 96 here (TREX_E_INVALID beyond: the kernel stages 96 observation columns per sample). */
 int trex_policy_minibatch_stats(TrexPolicy *policy, const float *adv_dev, int64_t num_samples, const int64_t *perm_dev,
                                 int num_minibatches, int mb, float *stats_out_dev, void *stream);
 int trex_policy_minibatch_step(TrexPolicy *policy, float *theta_dev, float *grad_dev, float *m_dev, float *v_dev,

@@ -41,12 +41,15 @@ def main():
     torch.cuda.synchronize()
     cnt = torch.zeros(n, dtype=torch.int32, device=dev)
     b.contact_stats(cnt, None)
-    raw = dbg.cpu().numpy()[4096:4096 + 14 * n].reshape(14, n)
+    full = dbg.cpu().numpy()[4096:4096 + 16 * n].reshape(16, n)
+    raw = full[:14]
+    alive, lamnz = full[14], full[15]    # point slots alive / holding an impulse at the start of a sweep, summed over the 300 sweeps
     env_of_wave = raw[11].astype(np.int64)          # the launch is balanced like the product's: wave k runs env perm[k]
     c = cnt.cpu().numpy()[env_of_wave]              # contacts of the env each wave ran
     d = raw[:9].copy()
     sub = raw[9:11]                      # contact generation split: [broad phase + table, scan]; d[1] = the rest
     sel = raw[12:14] if raw.shape[0] >= 14 else np.zeros((2, n))   # [deepest vertices + set-up, fill + passes] (K >= 2 path)
+    selp = sel
     d[1] += sub.sum(0) + sel.sum(0)
     tot = d.sum(0)
     print("waves %d, contacts per env mean %.2f max %d" % (n, c.mean(), c.max()))
@@ -65,6 +68,9 @@ def main():
             rows = 25 + 3 * c[sel].mean()
             print("envs with %2d..%2d contacts: %5d  wave cycles mean %.3g max %.3g; sweeps mean %.3g = %.1f cycles per row visit" % (
                 lo_, hi_, sel.sum(), tot[sel].mean(), tot[sel].max(), d[7][sel].mean(), d[7][sel].mean() / (300 * rows)))
+            if c[sel].sum() > 0:
+                print("    of their point slots, alive at the start of a sweep: %.1f %%; holding a normal impulse: %.1f %%" % (
+                    100 * alive[sel].sum() / (300.0 * c[sel].sum()), 100 * lamnz[sel].sum() / (300.0 * c[sel].sum())))
 
 
     # (workgroup k shares its SIMD with k +- 1024 ...)
@@ -79,6 +85,8 @@ def main():
             mates = [(w + 1024 * k) % 4096 for k in (1, 2, 3)]
             print("  %.3g %2d %2d | %.3g %.3g %.3g %.3g | %s" % (tot[w], c[w], on_stop[w], d[7][w], d[1][w], d[3][w], d[6][w],
                   " ".join("(%.3g, %d, %d)" % (tot[m_], c[m_], on_stop[m_]) for m_ in mates)))
+            print("      contact gen: table %.3g scan %.3g set-up %.3g fill+passes %.3g output %.3g; live points per sweep %.2f" % (
+                sub[0][w], sub[1][w], selp[0][w], selp[1][w], d[1][w] - sub[:, w].sum() - selp[:, w].sum(), alive[w] / 300.0))
         for k in range(0, 6):
             sel = on_stop == k if k < 5 else on_stop >= k
             if sel.any():

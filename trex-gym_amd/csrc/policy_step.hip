@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void act_kernel(ActArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int net = wave & 1, tile = wave >> 1;          // net 0: policy, 1: value
   const int D = g.lay.D, A = g.lay.A;
-  const int Dp = (D + 1) & ~1;          // K of the first layer, padded to the MFMA's k = 2
+  const int Dp8 = (D + 7) & ~7;         // K of the first layer, padded to four MFMA k-steps (k = 2 each); X is zero from column D on
   float *th = lds;                                       // [count] parameters
   float *Xall = lds + ((g.lay.count + 3) & ~3);          // [ACT_TILES][TILE][MAXD + 1] normalised observations (+ zero pad)
   {
@@ -101,22 +101,22 @@ __global__ __launch_bounds__(256) void act_kernel(ActArgs g) {
   // ---- stage the tiles: normalise, clip, keep a copy for the rollout buffer
   const int eb = blockIdx.x * (ACT_TILES * TILE);
   constexpr int UX = 10;      // 19 elements per thread at D = 75: two trips
-  for (int idx0 = tid; idx0 < ACT_TILES * TILE * Dp; idx0 += 256 * UX) {
+  for (int idx0 = tid; idx0 < ACT_TILES * TILE * Dp8; idx0 += 256 * UX) {
     float raw[UX], mean[UX], rstd[UX];
     int ii[UX], kk[UX];
     bool ok[UX];
 #pragma unroll
     for (int u = 0; u < UX; u++) {
       const int idx = idx0 + 256 * u;
-      ii[u] = idx / Dp; kk[u] = idx - ii[u] * Dp;
-      ok[u] = idx < ACT_TILES * TILE * Dp && kk[u] < D && eb + ii[u] < g.n;
+      ii[u] = idx / Dp8; kk[u] = idx - ii[u] * Dp8;
+      ok[u] = idx < ACT_TILES * TILE * Dp8 && kk[u] < D && eb + ii[u] < g.n;
       const int kc = kk[u] < D ? kk[u] : 0;
       raw[u] = ok[u] ? g.rows[(size_t)(eb + ii[u]) * g.row_stride + kc] : 0.f;
       mean[u] = g.norm[kc]; rstd[u] = g.norm[D + kc];
     }
 #pragma unroll
     for (int u = 0; u < UX; u++) {
-      if (idx0 + 256 * u >= ACT_TILES * TILE * Dp) continue;
+      if (idx0 + 256 * u >= ACT_TILES * TILE * Dp8) continue;
       float x = 0.f;
       if (ok[u]) {
         x = fminf(fmaxf((raw[u] - mean[u]) * rstd[u], -g.clip_obs), g.clip_obs);
@@ -147,15 +147,21 @@ __global__ __launch_bounds__(256) void act_kernel(ActArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; r++) h1[u][r] = b1[32 * u + rowmap(r, h)];
   }
-#pragma unroll 4
-  for (int kk = 0; kk < Dp; kk += 2) {
-    const int k = kk + h;
-    const float b = X[col * (MAXD + 1) + k];         // (k = D on the pad column: 0)
-    const int kc = k < D ? k : D - 1;                // (its weight row does not exist: any finite value, times 0)
+  // four k-steps per trip: their 12 LDS operand reads are issued together, then the 8 MFMAs (one k-step at a time,
+  // every MFMA waited for its own LDS round trip: 3.3 us of the kernel)
+  for (int k0 = 0; k0 < Dp8; k0 += 8) {
+    float a0[4], a1[4], b[4];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
-      const float a = W1[kc * HID + 32 * u + col];
-      h1[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, h1[u], 0, 0, 0);
+    for (int j = 0; j < 4; j++) {
+      const int k = k0 + 2 * j + h;
+      b[j] = X[col * (MAXD + 1) + k];                  // (zero from column D on)
+      const int kc = k < D ? k : D - 1;                // (such a weight row does not exist: any finite value, times 0)
+      a0[j] = W1[kc * HID + col]; a1[j] = W1[kc * HID + 32 + col];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      h1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b[j], h1[0], 0, 0, 0);
+      h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b[j], h1[1], 0, 0, 0);
     }
   }
 #pragma unroll

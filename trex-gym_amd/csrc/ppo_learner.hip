@@ -158,7 +158,7 @@ __global__ __launch_bounds__(128) void learn_grad_kernel(LearnArgs g) {
   float *ACT = lds + L.buf + net * 2 * HID * TS, *DEL = ACT + HID * TS;
   float *out = g.partial + (size_t)blockIdx.x * g.stride;
   const float inv_mb = 1.0f / (float)g.mb;
-  const int Dp = (D + 1) & ~1;
+  const int Dp8 = (D + 7) & ~7;     // (<= XC: the host entry refuses obs_dim > 96)
   // ================================================================ forward
   f32x16 h1[2], h2[2];
 #pragma unroll
@@ -166,13 +166,20 @@ __global__ __launch_bounds__(128) void learn_grad_kernel(LearnArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; r++) h1[u][r] = b1[32 * u + rowmap(r, h)];
   }
-#pragma unroll 4
-  for (int kk = 0; kk < Dp; kk += 2) {
-    const int k = kk + h;
-    const float b = X[col * XS + k];                  // (zero beyond D)
-    const int kc = k < D ? k : D - 1;
+  for (int k0 = 0; k0 < Dp8; k0 += 8) {                // four k-steps per trip (policy_step.hip, act_kernel)
+    float a0[4], a1[4], b[4];
 #pragma unroll
-    for (int u = 0; u < 2; u++) h1[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(W1[kc * HID + 32 * u + col], b, h1[u], 0, 0, 0);
+    for (int j = 0; j < 4; j++) {
+      const int k = k0 + 2 * j + h;
+      b[j] = X[col * XS + k];                          // (zero from column D on; XC = 96 columns are staged)
+      const int kc = k < D ? k : D - 1;
+      a0[j] = W1[kc * HID + col]; a1[j] = W1[kc * HID + 32 + col];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      h1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b[j], h1[0], 0, 0, 0);
+      h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b[j], h1[1], 0, 0, 0);
+    }
   }
 #pragma unroll
   for (int u = 0; u < 2; u++) {
@@ -560,6 +567,7 @@ int trex_policy_minibatch_step(TrexPolicy *p, float *theta_dev, float *grad_dev,
       !perm_dev || !adv_stats_dev)
     return trex_fail(TREX_E_INVALID, "trex_policy_minibatch_step: null argument");
   if (mb <= 0 || first < 0 || num_samples <= 0) return trex_fail(TREX_E_INVALID, "trex_policy_minibatch_step: bad sizes");
+  if (p->D > 96) return trex_fail(TREX_E_INVALID, "trex_policy_minibatch_step: the learner stages 96 observation columns (obs_dim <= 96)");
   TrexDeviceGuard guard(p->device);
   const size_t P = (size_t)p->lay.count, N = (size_t)num_samples;
   BUF_TRY(theta_dev, P * sizeof(float), "trex_policy_minibatch_step: theta");

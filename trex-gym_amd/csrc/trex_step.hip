@@ -582,6 +582,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
 
 #if TREX_STAMPS
   unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+  int stamp_alive = 0, stamp_lamnz = 0;
   if (args.debug && threadIdx.x == 0) args.debug[4096 + 11 * args.n_envs + blockIdx.x] = (float)env;   // the env of this wave
 #endif
   // Episode limit of the harness (the reference never terminates, trex_env.py:183-184; a VecEnv auto-resets): the env
@@ -1569,14 +1570,18 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
 // A point with no normal impulse before its visit (lam_n = 0) and none after it (lam_n + y_n <= 0) changes
 // nothing: its normal row gives d = 0, its friction rows are clamped to 0 and hold 0 already (they were visited
 // after the normal row lost its impulse). Most candidate points are like that - inside the 2 cm margin, not
-// pressing. ONE vector test over all normal-row lanes (`alive_points`) therefore precedes the point blocks: a dead
+// pressing. ONE vector test over all normal-row lanes therefore precedes the point blocks: a dead
 // point costs a scalar bit test, and the test is repeated after every point that was processed (it changed y).
 // Bitwise the same result as visiting every row: the skipped updates would add B * 0.
-// A live point is one hand-placed block of 27 slots. Like the motor rows, its rows work with bounds SHIFTED by the
+// A live point is one hand-placed block of 24 slots. Like the motor rows, its rows work with bounds SHIFTED by the
 // impulse: normal d = max(y, -lam) (one instruction; lam + d = 0 exactly when the contact lets go), friction
 // d = med3(y, -hi - lam, hi - lam) with hi = mu * the new normal impulse, the two shifted bounds formed once for
 // both friction lanes; the three changes are captured by v_writelane - which doubles as the wait state between a
-// v_med3 and the v_readlane of its result - and committed with one add.
+// v_med3 and the v_readlane of its result - into `dvc`, which is committed ONCE per sweep after the last point (a
+// row is visited once per sweep, and a point block reads lam on its own three lanes only: 27 slots with a
+// v_mov 0 / v_add per point). For the same reason the liveness of the points still to come needs nothing but
+// the new y: lam != 0 is settled per sweep (`lamnz`), and y > -lam is ONE compare against `thr` = -lam on the
+// normal lanes of the live slots, +inf elsewhere (formed per sweep), so vcc needs no masking.
 #define TREX_POINT_TEXT(P)                                                                             \
                "s_bitcmp1_b64 %[al], %[ln" #P "]\n\t"                                                  \
                "s_cbranch_scc0 " #P "f\n\t"                                                            \
@@ -1585,7 +1590,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
                "v_add_f32_e32 %[t], %[lam], %[d]\n\t"                                                  \
                "v_readlane_b32 %[sd], %[d], %[ln" #P "]\n\t"                                           \
                "v_readlane_b32 %[snl], %[t], %[ln" #P "]\n\t"                                          \
-               "v_mov_b32_e32 %[dv], 0\n\t"                /* the point's three impulse changes are captured here */ \
+               "s_nop 0\n\t"                                                                           \
                "v_fmac_f32_e32 %[y], %[sd], %[b0" #P "]\n\t"                                           \
                "v_mul_f32_e32 %[hi], %[snl], %[mu]\n\t"                                                \
                /* friction bounds -hi - lam, hi - lam for both friction lanes at once */               \
@@ -1604,16 +1609,13 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
                "s_nop 1\n\t"                                                                           \
                "v_fmac_f32_e32 %[y], %[sd], %[b2" #P "]\n\t"                                           \
                "v_writelane_b32 %[dv], %[sd], %[ly" #P "]\n\t"                                         \
-               /* commit, and which points can change anything now */                                  \
-               "v_add_f32_e32 %[lam], %[lam], %[dv]\n\t"                                               \
-               "v_cmp_neq_f32_e64 %[tmp], 0, %[lam]\n\t"                                               \
-               "v_cmp_gt_f32_e64 vcc, %[y], -%[lam]\n\t"               /* lam + y > 0 */              \
-               "s_or_b64 %[al], vcc, %[tmp]\n\t"                                                       \
-               "s_and_b64 %[al], %[al], %[nrm]\n\t"                                                    \
+               /* which of the points still to come can change anything now */                         \
+               "v_cmp_gt_f32_e32 vcc, %[y], %[thr]\n\t"                   /* lam + y > 0 */           \
+               "s_or_b64 %[al], vcc, %[lnz]\n\t"                                                       \
                #P ":\n\t"
-#define TREX_POINT_OUTS [y] "+v"(y), [lam] "+v"(lam), [al] "+s"(alive), [t] "=&v"(pt_), [d] "=&v"(pd_), [hi] "=&v"(ph_), \
-                        [dv] "=&v"(pv_), [snl] "=&s"(psn_), [sd] "=&s"(psd_), [tmp] "=&s"(ptm_)
-#define TREX_POINT_INS [mu] "v"(mu), [nrm] "s"(nrm_mask)
+#define TREX_POINT_OUTS [y] "+v"(y), [dv] "+v"(dvc), [al] "+s"(alive), [t] "=&v"(pt_), [d] "=&v"(pd_), [hi] "=&v"(ph_), \
+                        [snl] "=&s"(psn_), [sd] "=&s"(psd_)
+#define TREX_POINT_INS [lam] "v"(lam), [mu] "v"(mu), [thr] "v"(thr), [lnz] "s"(lamnz)
 #define TREX_POINT_OPS(P, S) [b0##P] "v"(Bc[3 * (S)]), [b1##P] "v"(Bc[3 * (S) + 1]), [b2##P] "v"(Bc[3 * (S) + 2]),     \
                              [ln##P] "n"(KROW_LANE(3 * (S))), [lx##P] "n"(KROW_LANE(3 * (S) + 1)), [ly##P] "n"(KROW_LANE(3 * (S) + 2))
 // (several point slots per asm statement: the compiler closes every statement with an s_nop of its own)
@@ -1625,8 +1627,8 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
 #define TREX_POINTS1(S)                                                                                \
   asm volatile(TREX_POINT_TEXT(0) : TREX_POINT_OUTS : TREX_POINT_INS, TREX_POINT_OPS(0, S) : "vcc", "scc");
       // lanes that hold the normal row of a live point slot
-      const unsigned long long nrm_mask = __ballot(lt >= CLANE0 && (lt - CLANE0) % 3 == 0 && (lt - CLANE0) / 3 >= s0);
-      auto alive_points = [&]() { return nrm_mask & (__ballot(lam != 0.f) | __ballot(y > -lam)); };   // (two v_cmp + s_or)
+      const bool is_nrm = lt >= CLANE0 && (lt - CLANE0) % 3 == 0 && (lt - CLANE0) / 3 >= s0;
+      const unsigned long long nrm_mask = __ballot(is_nrm);
 #if TREX_PRIO_MODE == 1
       set_sweep_priority(nc);
 #endif
@@ -1801,14 +1803,31 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
           }
         }
         // the live point slots, in order (dead slots have no bit in `alive`)
-        unsigned long long alive = nrm_mask != 0ull ? alive_points() : 0ull;   // (an airborne env has no point rows at all)
+        unsigned long long alive = 0ull, lamnz = 0ull;
+        if (nrm_mask != 0ull) {   // (an airborne env has no point rows at all)
+          lamnz = nrm_mask & __ballot(lam != 0.f);
+          alive = lamnz | (nrm_mask & __ballot(y > -lam));
+        }
+#if TREX_STAMPS   // per wave: point slots alive / holding an impulse at the start of a sweep, summed over the launch
+        stamp_alive += __popcll(alive); stamp_lamnz += __popcll(lamnz);
+#endif
         if (alive != 0ull) {
-          float pt_, pd_, ph_, pv_;
+          float pt_, pd_, ph_;
           int psn_, psd_;
-          unsigned long long ptm_;
-          if (s0 < 7) { TREX_POINTS3(0) TREX_POINTS3(3) TREX_POINTS1(6) }
-          if (s0 < 10) { TREX_POINTS3(7) }
-          TREX_POINTS3(10)
+          const float thr = is_nrm ? -lam : __builtin_inff();
+          float dvc = 0.f;      // the impulse changes of this sweep's point rows, by lane
+          // (a dead point costs its bit test and a TAKEN branch, ~16 cycles, and of the slots of an env on 12 points one
+          // or two are alive in a sweep: a group of slots without a live one is passed in one test)
+          constexpr unsigned long long NB = 1ull << CLANE0;      // normal row of slot S: lane CLANE0 + 3 S
+          constexpr unsigned long long G0 = NB * 0111ull, G3 = G0 << 9, G6 = NB << 18, G7 = G0 << 21, G10 = G0 << 30;
+          if ((alive & (G0 | G3 | G6)) != 0ull) {
+            if ((alive & G0) != 0ull) { TREX_POINTS3(0) }
+            if ((alive & G3) != 0ull) { TREX_POINTS3(3) }
+            if ((alive & G6) != 0ull) { TREX_POINTS1(6) }
+          }
+          if ((alive & G7) != 0ull) { TREX_POINTS3(7) }
+          if ((alive & G10) != 0ull) { TREX_POINTS3(10) }
+          lam += dvc;
         }
       }
 #undef TREX_ROW
@@ -1916,6 +1935,12 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
 #undef REROW
   }
 
+#if TREX_STAMPS
+  if (args.debug && threadIdx.x == 0) {
+    args.debug[4096 + 14 * args.n_envs + blockIdx.x] = (float)stamp_alive;
+    args.debug[4096 + 15 * args.n_envs + blockIdx.x] = (float)stamp_lamnz;
+  }
+#endif
   // ---- end of the env-step: outputs
   if (RESET || !time_up) finish_step();
   if (env_bad && !time_up) to_start_pose();     // (a time-limit reset already left a sound state)
