@@ -73,6 +73,15 @@ def main():
                     100 * alive[sel].sum() / (300.0 * c[sel].sum()), 100 * lamnz[sel].sum() / (300.0 * c[sel].sum())))
 
 
+    # how well do the balance keys predict a wave's work? least squares of the wave cycles on (contacts) and on
+    # (contacts, live points per sweep); meaningful where every wave is alone on its SIMD (<= 1024 envs)
+    L = alive / 300.0
+    for name, cols in (("contacts", [c]), ("contacts + live points per sweep", [c, L])):
+        A = np.stack([np.ones(n)] + [np.asarray(x, dtype=np.float64) for x in cols], 1)
+        coef, *_ = np.linalg.lstsq(A, tot, rcond=None)
+        res = tot - A @ coef
+        print("fit of the wave cycles on %s: coefficients %s, residual std %.3g (of std %.3g), worst %.3g" % (
+            name, " ".join("%.3g" % v for v in coef), res.std(), tot.std(), np.abs(res).max()))
     # (workgroup k shares its SIMD with k +- 1024 ...)
     if n == 4096:
         order = np.argsort(tot)[::-1][:8]

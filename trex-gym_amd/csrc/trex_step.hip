@@ -523,11 +523,16 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
     else if (v == 2) __builtin_amdgcn_s_setprio(2);
     else __builtin_amdgcn_s_setprio(3);
   };
+#ifndef TREX_TREE_HEAVY
+#define TREX_TREE_HEAVY 12
+#endif
+  int prio_nc = 0;      // contact points of the env's last substep (before the first one: of its last step)
   auto set_tree_priority = [&](int substep) {   // outside the sweeps: the pairs take turns
+    if (TREX_TREE_HEAVY > 0 && prio_nc >= TREX_TREE_HEAVY) { __builtin_amdgcn_s_setprio(3); return; }
     if (aged_launch && ((wave_pair + substep) & 1)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
   };
 #if TREX_PRIO_MODE == 1
-  if (!RESET) set_tree_priority(0);
+  if (!RESET) { prio_nc = flags_in & 255; set_tree_priority(0); }
 #endif
 
   const float floor_z = M->prm[TP_FLOOR_Z], margin = M->prm[TP_CONTACT_MARGIN];
@@ -1837,6 +1842,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
       lam -= lam_c;
     }
 #if TREX_PRIO_MODE == 1
+    prio_nc = nc;
     set_tree_priority(sub);
 #endif
     STAMP(7);
@@ -2008,6 +2014,9 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
       // flips the phase
       int32_t *B = args.bal;
       const int w = bal_phase ^ 1;
+      // (filed under the contact count. Not better, measured: under a work class from a least-squares fit of the
+      // lone wave's cycles - 470 k + 11.8 k per contact point + 96 k per point ALIVE in a sweep, scripts/wave_phases.py
+      // 1024, residual 19 k against 37 k for the count alone - in 32 classes of 16 k cycles: 11.55 M against 11.59 M)
       const int bin = stat_nc < 0 ? 0 : (stat_nc >= TREX_BAL_BINS ? TREX_BAL_BINS - 1 : stat_nc);
       const int at = atomicAdd(&B[TREX_BAL_COUNTS + TREX_BAL_BINS * w + bin], 1);
       if (at < args.n_envs) B[TREX_BAL_LISTS + (size_t)(w * TREX_BAL_BINS + bin) * args.n_envs + at] = env;
