@@ -343,3 +343,18 @@ def test_policy_and_learner_kernels_at_other_dimensions():
         kw = dict(num_envs=8, obs_dim=6, act_dim=2, hidden=64, device=0); kw.update(bad)
         with pytest.raises(_capi.TrexError):
             _capi.Policy(**kw)
+    # the learner stages 96 observation columns per sample: a wider policy can act, but not learn natively
+    D2, n2 = 100, 64
+    kern2 = _capi.Policy(n2, D2, A, 64, 0)
+    pol2 = MlpPolicy(kern2.layout, kern2.param_count, torch.device(DEV))
+    rows2 = torch.randn(n2, D2 + 2, device=DEV)
+    kern2.set_stats(dict(obs_mean=np.zeros(D2), obs_var=np.ones(D2), obs_count=10.0, ret_mean=0.0, ret_var=1.0, ret_count=10.0))
+    a2, o2, l2, v2 = torch.empty(n2, A, device=DEV), torch.empty(n2, D2, device=DEV), torch.empty(n2, device=DEV), torch.empty(n2, device=DEV)
+    nz2 = torch.randn(n2, A, device=DEV)
+    kern2.act(pol2.theta, rows2, nz2, a2, o2, None, l2, v2)
+    with torch.no_grad():
+        torch.testing.assert_close(v2, pol2.value((rows2[:, :D2] / math.sqrt(1.0 + 1e-8)).clamp(-10, 10)), rtol=1e-5, atol=1e-5)
+    z = torch.zeros(n2, device=DEV)
+    with pytest.raises(_capi.TrexError, match="obs_dim <= 96"):
+        kern2.minibatch_step(pol2.theta, torch.zeros_like(pol2.theta), torch.zeros_like(pol2.theta), torch.zeros_like(pol2.theta), o2, a2,
+                             l2, v2, z, z, torch.arange(n2, device=DEV), 0, n2, torch.tensor([0.0, 1.0], device=DEV), loss_sums=None)
