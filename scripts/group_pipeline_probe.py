@@ -31,11 +31,22 @@ offset = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0     # stagger the grou
 sh = [s_.cuda_stream for s_ in streams]
 
 
+join = len(sys.argv) > 5 and sys.argv[5] == "join"      # a barrier between the groups after every step (what a library-internal split would have)
+evs = [torch.cuda.Event() for _ in range(G)]
+
+
 def run(t0, t1):
     for t in range(t0, t1):
         for g in range(G):
             e = envs[g]
             e.batch.step_rows(acts[g][t], e.rows, e._penalties, stream=sh[g], done=e.done)
+        if join:
+            for g in range(G):
+                evs[g].record(streams[g])
+            for g in range(G):
+                for h in range(G):
+                    if h != g:
+                        streams[g].wait_event(evs[h])
 
 
 if offset > 0:
@@ -50,4 +61,4 @@ t = time.perf_counter()
 run(pre, T)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t
-print("offset %.2f ms: G = %d groups of %d envs: %.3f M env-steps/s (%.4f ms per step of all %d envs)" % (offset, G, n // G, n * steps / dt / 1e6, dt / steps * 1e3, n), flush=True)
+print(("join every step, " if join else "") + "offset %.2f ms: G = %d groups of %d envs: %.3f M env-steps/s (%.4f ms per step of all %d envs)" % (offset, G, n // G, n * steps / dt / 1e6, dt / steps * 1e3, n), flush=True)
