@@ -23,6 +23,9 @@ __global__ __launch_bounds__(64) void k(float *out, long long *cyc, int sweeps, 
   float bsub = 1e-3f * (float)(tid % 5 - 2);
   float scratchv = 0.f;
   const long long t0 = __builtin_amdgcn_s_memtime();
+  // 16: the kernel's row with only the LOW HALF of the wave enabled (does a wave64 VALU instruction skip a half whose EXEC
+  // is 0?) - the compiler sets EXEC for the branch; the loop inside it is uniform
+  if (VARIANT != 16 || tid < 32)
 #pragma unroll 1
   for (int it = 0; it < sweeps; it++) {
     int vs = tid;
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(64) void k(float *out, long long *cyc, int sweeps, 
         const float sd = rl(d, L);
         y = __builtin_fmaf(B[j], sd, y);
         lam += (vs == L) ? d : 0.f;
-      } else if (VARIANT >= 8 && VARIANT <= 12) {
+      } else if ((VARIANT >= 8 && VARIANT <= 12) || VARIANT == 16) {
         // hand-placed rows of the round-2 kernel: bounds shifted by the impulse, d = med3(y, blo, bhi); the impulse
         // changes are captured in `dv` (lane L) by v_writelane and committed after the sweep
         //  8: the kernel's row        med3, writelane, readlane, s_nop 1, fmac                 (5 slots)
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(64) void k(float *out, long long *cyc, int sweeps, 
         // 12: the 7-slot row of before: add, med3, sub, writelane, readlane, s_nop 1, fmac
         float d_;
         int s_;
-        if (VARIANT == 8)
+        if (VARIANT == 8 || VARIANT == 16)
           asm volatile("v_med3_f32 %2, %0, %4, %5\n\tv_writelane_b32 %1, %3, %7\n\tv_readlane_b32 %3, %2, %7\n\ts_nop 1\n\tv_fmac_f32_e32 %0, %3, %6"
                        : "+v"(y), "+v"(dv), "=&v"(d_), "+s"(sprev) : "v"(blo), "v"(bhi), "v"(B[j]), "n"(1 + (j % 63)));
         else if (VARIANT == 9)
@@ -168,6 +171,7 @@ int main() {
   run<7>("7 short chain, bounds from lam", out, cyc, sweeps);
   run<12>("12 asm, 7 slots (add med3 sub wl rl nop1 fmac)", out, cyc, sweeps);
   run<8>("8 asm, 5 slots (med3 wl rl nop1 fmac)", out, cyc, sweeps);
+  run<16>("16 the same (8) with EXEC = the low 32 lanes", out, cyc, sweeps);
   run<9>("9 asm, 5 slots, s_nop 0 for the writelane", out, cyc, sweeps);
   run<10>("10 asm, 6 slots, s_nop 0 x2 for s_nop 1", out, cyc, sweeps);
   run<11>("11 asm, 6 slots, two v_mov for s_nop 1", out, cyc, sweeps);
