@@ -41,7 +41,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # (MI355X_MICROARCH.md, chip parameters + "v_fma_f32 (wave64) 2 cyc")
 VALU_ISSUE_PEAK_GIPS = 256 * 4 * 2.4 / 2.0   # 1228.8 G wave-instructions/s
 EPISODE_STEPS = 1000   # harness time limit (the reference never terminates, trex_env.py:183-184)
-EVENT_STRIDE = 4         # N > 1: HIP-event pairs around every 4th launch of the timed region (see run()); one GPU: ONE spanning pair
+GATHER_JOIN = os.environ.get("TREX_BENCH_GATHER_JOIN", "host")   # "host" | "stream": how the pipelined gather orders step t+2 behind gather t (sharding.PipelinedGather)
+EVENT_STRIDE = int(os.environ.get("TREX_BENCH_EVENT_STRIDE", "4"))         # N > 1: HIP-event pairs around every 4th launch of the timed region (see run()); one GPU: ONE spanning pair
 
 
 def _cpu_worker(args):
@@ -183,6 +184,27 @@ def _load_json(name):
     return json.load(open(p)) if os.path.exists(p) else None
 
 
+_REAL_STDOUT = None
+
+
+def _protect_stdout():
+    """The contract is ONE JSON line on stdout, and C libraries write to fd 1 behind Python's back (RCCL prints a
+    five-line version banner when its communicator is created): from here on fd 1 is stderr, and the line goes out
+    through a duplicate of the real stdout (_emit)."""
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
+
+
+def _emit(line):
+    if _REAL_STDOUT is None:
+        print(line, flush=True)
+    else:
+        sys.stdout.flush()
+        os.write(_REAL_STDOUT, (line + "\n").encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -241,6 +263,7 @@ def main():
             dist.destroy_process_group()
         return
 
+    _protect_stdout()
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()  # before the GPU is initialised (spawned workers never touch HIP)
@@ -261,7 +284,12 @@ def main():
         # ONE GPU (RCCL refuses two ranks per device); never a measurement.
         backend = os.environ.get("TREX_BENCH_BACKEND", "nccl")
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            # (TREX_BENCH_COMM_PRIORITY=1: the collective's stream at high priority. Measured with a world of one on one
+            # GPU - where the "gather" is a 4 us copy - it makes the chain of step launches SLOWER, 0.49 against 0.39 ms
+            # per step; default off)
+            opts = dist.ProcessGroupNCCL.Options()
+            opts.is_high_priority_stream = os.environ.get("TREX_BENCH_COMM_PRIORITY", "0") == "1"
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=opts)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     rccl_ranks = dist.get_world_size() if dist.is_initialized() else 1
@@ -341,13 +369,14 @@ def main():
                     span[1].record()
             if world > 1:
                 if gather_mode[0] == "pipelined":
-                    # overlaps the next step; a consumer sees the rows one step late and orders ITSELF behind the
-                    # gather (none here): the compute stream only waits for the block it is about to rewrite
-                    env.all_gather_rows_pipelined(wait=False)
+                    # overlaps the next step; a consumer sees the rows one step late. The block step t+2 rewrites is the one
+                    # gather t reads: the HOST waits for gather t here, before it launches step t+2 (a stream wait on the
+                    # compute stream costs the chain of step launches 40 % on this ROCm build: scripts/sync_cost_probe.py)
+                    env.all_gather_rows_pipelined(wait=False, join=GATHER_JOIN)
                 else:
                     env.all_gather_rows()             # blocking: the consumer sees this step's rows
             elif force_gather:   # one-GPU rehearsal of the collective call itself (RCCL, world of 1)
-                pipe.push(env.rows, copy=False, wait=False)
+                pipe.push(env.rows, copy=False, wait=False, join=GATHER_JOIN)
 
     def fence():
         torch.cuda.synchronize()
@@ -500,7 +529,7 @@ def main():
                              "row_block": "[n, 3J+2] f32 = obs | reward | done"}
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out))
+        _emit(json.dumps(out))
     if world > 1 or under_launcher:
         dist.destroy_process_group()
 

@@ -109,7 +109,7 @@ def test_two_rank_gloo_gather_equals_single_process(n_global):
     assert done.tolist() == [(i + steps - 1) % 3 == 0 for i in range(n_global)]
 
 
-def _pipe_worker(rank, world, port, ret, in_place=False):
+def _pipe_worker(rank, world, port, ret, in_place=False, join="stream"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -128,7 +128,7 @@ def _pipe_worker(rank, world, port, ret, in_place=False):
             blocks[t & 1].copy_(local)                    # "step t" writes block t & 1 ...
             # ... which is gathered where it lies. NO consumer-side wait here: push() itself orders the producer
             # behind the gather that reads the block the next step rewrites (and thereby the returned rows too)
-            prev = pipe.push(blocks[t & 1], copy=False, wait=False)
+            prev = pipe.push(blocks[t & 1], copy=False, wait=False, join=join)
         else:
             prev = pipe.push(local)
             local.fill_(-1.0)    # the caller may overwrite its rows at once (they were staged)
@@ -140,13 +140,14 @@ def _pipe_worker(rank, world, port, ret, in_place=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("in_place", [False, True])
+@pytest.mark.parametrize("in_place", [False, True, "host"])
 def test_pipelined_gather_returns_the_previous_step(tmp_path, in_place):
     """The overlapped all-gather of bench.py --gpus N: call t returns the rows of call t-1, from every rank -
-    staged, or gathered in place from a producer that alternates between two row blocks."""
+    staged, or gathered in place from a producer that alternates between two row blocks (with the stream join or the host
+    join that bench.py uses)."""
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_pipe_worker, args=(2, _free_port(), ret, in_place), nprocs=2, join=True)
+    mp.spawn(_pipe_worker, args=(2, _free_port(), ret, bool(in_place), "host" if in_place == "host" else "stream"), nprocs=2, join=True)
     got = ret["got"]
     assert got[0] is None
     for t in range(1, 5):
@@ -160,6 +161,13 @@ class _FakeWork:
 
     def wait(self):
         self.log.append(("wait", self.t))
+
+    def is_completed(self):          # (join="host": polled by the host; reports done on the second query)
+        self.polls = getattr(self, "polls", 0) + 1
+        if self.polls >= 2:
+            self.log.append(("hostwait", self.t))
+            return True
+        return False
 
 
 @pytest.mark.parametrize("wait", [False, True])
@@ -215,3 +223,30 @@ def test_staged_gather_protects_its_staging_block(monkeypatch):
     for t in range(2, 5):
         i_gather_t = next(i for i, e in enumerate(log) if e[0] == "gather" and e[1] == t)
         assert ("wait", t - 2) in log[:i_gather_t]       # before stage[t & 1] was refilled for gather t
+
+
+def test_in_place_gather_with_the_host_join_orders_the_same_without_a_stream_wait(monkeypatch):
+    """join="host" (what bench.py --gpus N runs: a stream wait on the compute stream costs the chain of step launches
+    40 % on this ROCm build, scripts/sync_cost_probe.py): push(t+1) returns only when gather t has COMPLETED - observed by
+    polling the work handle on the host - so step t+2 is enqueued behind the last reader of its block, and no
+    work.wait() (a wait on the caller's stream) is ever issued."""
+    from trex_gym import sharding
+    log = []
+
+    def fake_all_gather(out, src, group=None, async_op=False):
+        t = sum(1 for e in log if e[0] == "gather")
+        log.append(("gather", t, src.data_ptr()))
+        return _FakeWork(log, t)
+
+    monkeypatch.setattr(sharding.dist, "all_gather_into_tensor", fake_all_gather)
+    pipe = sharding.PipelinedGather(3, 5, 2, torch.float32, "cpu")
+    blocks = [torch.zeros(3, 5), torch.zeros(3, 5)]
+    for t in range(6):
+        log.append(("write", t, blocks[t & 1].data_ptr()))
+        pipe.push(blocks[t & 1], copy=False, wait=False, join="host")
+    assert not any(e[0] == "wait" for e in log)
+    for t in range(2, 6):
+        i_write = log.index(("write", t, blocks[t & 1].data_ptr()))
+        i_gather = next(i for i, e in enumerate(log) if e[0] == "gather" and e[1] == t - 2)
+        done = [i for i, e in enumerate(log) if e == ("hostwait", t - 2)]
+        assert done and i_gather < min(done) < i_write, (t, log)

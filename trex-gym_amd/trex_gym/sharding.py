@@ -6,6 +6,8 @@ contiguous env-id ranges with no data-path collective. The only exchange is the 
 (torch.distributed.all_gather_into_tensor: RCCL over xGMI with backend "nccl" on ROCm, gloo in the
 CPU tests). Device-agnostic on purpose: nothing here touches HIP.
 """
+import time
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -97,7 +99,15 @@ class PipelinedGather:
     between the launches of step t+1 and step t+2 - makes the caller's stream wait for G(t), always, whatever
     `wait` says. That is the one cross-stream wait per step, and it is the one that orders step t+2 behind the last
     reader of the block it rewrites. (Round 2 waited for G(t) at the top of push(t+2), AFTER step t+2 had been
-    enqueued: a write-after-read race whenever a gather outlives the following step.)"""
+    enqueued: a write-after-read race whenever a gather outlives the following step.)
+
+    join="host": the same ordering, enforced by the HOST - push(t+1) returns only when gather t has completed
+    (the work handle's completion query), so the caller's stream gets no wait of its own. On this ROCm build a
+    hipStreamWaitEvent on the stream that carries the step launches costs the chain of launches far more than the
+    wait itself (scripts/sync_cost_probe.py, one MI355X: back-to-back step launches 0.360 ms per step; with the
+    fork to a side stream 0.383; with the compute stream ALSO waiting for an event of the side stream 0.523,
+    whichever earlier step's event it is; with the host waiting instead 0.364). The host then runs at most two
+    steps ahead of the GPU, which a 0.35 ms step launch does not notice."""
 
     def __init__(self, rows_local, cols, world_size, dtype, device, group=None):
         self.world, self.group = int(world_size), group
@@ -106,8 +116,15 @@ class PipelinedGather:
         self.work = [None, None]
         self.k = 0
 
-    def push(self, local, copy=True, wait=True):
+    @staticmethod
+    def _host_wait(work):
+        while not work.is_completed():       # (an event query; the gather it waits for ended a step launch ago)
+            time.sleep(0)
+
+    def push(self, local, copy=True, wait=True, join="stream"):
         """Launch the gather of `local`; returns the previous call's gathered rows (None on the first).
+        join: "stream" - waits are stream waits on the caller's stream (work.wait()); "host" - the host waits for the
+        completion of the gather instead (class note). The ordering guarantees are the same.
         copy=False: `local` is gathered in place; the caller must not write it before the NEXT push() has returned
         (that push orders the caller's stream behind this gather) - a producer alternating between two row blocks
         and pushing after every step satisfies that by construction.
@@ -118,7 +135,7 @@ class PipelinedGather:
         if copy:
             # stage[k] was last read by the gather of two calls ago (complete unless wait=False skipped its wait)
             if self.work[k] is not None:
-                self.work[k].wait()
+                self._host_wait(self.work[k]) if join == "host" else self.work[k].wait()
             self.stage[k].copy_(local)
             src = self.stage[k]
         # (out[k], last written by the gather of two calls ago, is rewritten behind it: the communicator's stream is
@@ -129,7 +146,7 @@ class PipelinedGather:
             return None
         if wait or not copy:
             # in place: the block the producer's NEXT step rewrites is the one work[prev] is reading
-            self.work[prev].wait()
+            self._host_wait(self.work[prev]) if join == "host" else self.work[prev].wait()
         return self.out[prev]
 
     def last_work(self):

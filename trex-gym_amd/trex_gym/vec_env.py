@@ -155,7 +155,7 @@ class TrexVecEnv(spaces.Env):       # gym.Env where gym is importable; the surfa
                                                     self.process_group, out=self._gather_buf)
         return self._gather_buf
 
-    def all_gather_rows_pipelined(self, rows=None, wait=True):
+    def all_gather_rows_pipelined(self, rows=None, wait=True, join="stream"):
         """Like all_gather_rows, but the collective overlaps the next step: returns the rows gathered by the
         PREVIOUS call (None on the first). See sharding.PipelinedGather."""
         rows = self.rows if rows is None else rows
@@ -166,7 +166,7 @@ class TrexVecEnv(spaces.Env):       # gym.Env where gym is importable; the surfa
                 raise ValueError("pipelined gather needs equal shards")
             self._pipe = sharding.PipelinedGather(self.num_envs, rows.shape[1], self.world_size, rows.dtype,
                                                   self.device, self.process_group)
-        return self._pipe.push(rows, copy=not (rows is self.rows and len(self._row_blocks) > 1), wait=wait)
+        return self._pipe.push(rows, copy=not (rows is self.rows and len(self._row_blocks) > 1), wait=wait, join=join)
 
     def all_gather_obs(self):
         """[global N, 3J]: the observation columns of all_gather_rows()."""
