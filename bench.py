@@ -278,6 +278,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if os.environ.get("TREX_BENCH_COMPUTE_STREAM") == "1":     # rehearsal switch: the step launches on a stream of their own
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))   # (then a side stream's kernels land on another hardware queue)
     if world > 1 or under_launcher:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" IS RCCL on ROCm. TREX_BENCH_BACKEND=gloo: rehearsal of the N>1 control flow with several ranks on
@@ -298,6 +300,8 @@ def main():
     overrides = {k: float(v) for k, v in (p.split("=") for p in args.param)}
     env = TrexVecEnv(n_global, device=dev, rank=rank, world_size=world, params=overrides, collision=args.collision,
                      max_episode_steps=EPISODE_STEPS, row_buffers=2 if (world > 1 or under_launcher) else 1)
+    if "TREX_BENCH_BALANCE" in os.environ:      # rehearsal switch: -1 auto, 0 off, 1 on (trex_batch_set_wave_balance)
+        env.batch.set_wave_balance(int(os.environ["TREX_BENCH_BALANCE"]))
     if args.collision != "hulls":
         overrides = dict(overrides, collision=args.collision)
     n_local = env.num_envs
