@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <fstream>
 #include <functional>
+#include <set>
 #include <sstream>
 #include <stdexcept>
 
@@ -69,6 +70,9 @@ std::vector<double> parse_doubles(const std::string &s) {
   for (;;) {
     double v = std::strtod(p, &e);
     if (e == p) break;
+    // strtod reads "nan", "inf", "1e999": a non-finite vertex, mass, inertia, origin or limit would put every env of the
+    // batch on the containment path - the file is refused instead
+    if (!std::isfinite(v)) throw LoadError(TREX_E_PARSE, "non-finite number '" + std::string(p, (size_t)(e - p)) + "'");
     out.push_back(v);
     p = e;
   }
@@ -81,7 +85,12 @@ Vec3 parse_vec3(const std::string &s, const char *what) {
 }
 double attr_double(const xmlmin::Node *n, const char *name, double dflt) {
   const std::string *a = n ? n->attr(name) : nullptr;
-  return a ? std::strtod(a->c_str(), nullptr) : dflt;
+  if (!a) return dflt;
+  char *e = nullptr;
+  const double v = std::strtod(a->c_str(), &e);
+  if (e == a->c_str()) throw LoadError(TREX_E_PARSE, std::string("attribute ") + name + "='" + *a + "' is not a number");
+  if (!std::isfinite(v)) throw LoadError(TREX_E_PARSE, std::string("attribute ") + name + "='" + *a + "' is not finite");
+  return v;
 }
 Tf parse_origin(const xmlmin::Node *parent) {
   Tf t;
@@ -261,10 +270,18 @@ HostModel load_model(const std::string &urdf_path, const char *collisions_dir, i
       }
       for (auto *v : l->all("visual"))
         if (const xmlmin::Node *g = v->child("geometry"))
-          if (const xmlmin::Node *m = g->child("mesh")) u.visuals.push_back({m->attr_or("filename", ""), parse_origin(v)});
+          if (const xmlmin::Node *m = g->child("mesh")) {
+            // (the origin first: if parse_origin throws INSIDE the braced initialiser, g++ 11 leaks the string member
+            // that was already built - found by tests/test_host_sanitize.py)
+            const Tf o = parse_origin(v);
+            u.visuals.push_back({m->attr_or("filename", ""), o});
+          }
       for (auto *v : l->all("collision"))
         if (const xmlmin::Node *g = v->child("geometry"))
-          if (const xmlmin::Node *m = g->child("mesh")) u.collisions.push_back({m->attr_or("filename", ""), parse_origin(v)});
+          if (const xmlmin::Node *m = g->child("mesh")) {
+            const Tf o = parse_origin(v);
+            u.collisions.push_back({m->attr_or("filename", ""), o});
+          }
       links.push_back(u);
     }
     if (links.empty()) throw LoadError(TREX_E_PARSE, urdf_path + ": no links");
@@ -327,14 +344,20 @@ HostModel load_model(const std::string &urdf_path, const char *collisions_dir, i
     // ---- merge fixed joints: bodies in depth-first document order (parent index < child index)
     struct Body { std::string head; int parent; int joint; Tf tf_parent; std::vector<std::pair<int, Tf>> members; };
     std::vector<Body> bodies;
+    std::set<std::string> visited;
     std::function<void(const std::string &, int, int, const Tf &, const Tf &)> build =
         [&](const std::string &head, int parent, int joint, const Tf &tf_head, const Tf &tf_parent) {
           int idx = (int)bodies.size();
+          // (refused HERE, not after the walk: `build` recurses per moving body, and a caller-named file may chain any number)
+          if (idx >= kMaxBodies)
+            throw LoadError(TREX_E_UNSUPPORTED, "model has more than " + std::to_string(kMaxBodies) + " moving bodies, kernels support " + std::to_string(kMaxBodies));
           bodies.push_back({head, parent, joint, tf_parent, {}});
           std::vector<std::pair<int, Tf>> pending;  // revolute joints leaving this body
           std::vector<std::pair<std::string, Tf>> queue{{head, tf_head}};
           for (size_t qi = 0; qi < queue.size(); qi++) {
             auto [ln, tf] = queue[qi];
+            // a link reached twice has two parent joints or lies on a cycle below the root: the walk would never end
+            if (!visited.insert(ln).second) throw LoadError(TREX_E_PARSE, "link " + ln + " is the child of two joints (or lies on a cycle)");
             bodies[idx].members.push_back({link_index[ln], tf});
             for (int k : children[ln]) {
               if (joints[k].type == "fixed") queue.push_back({joints[k].child, compose(tf, joints[k].origin)});

@@ -1,6 +1,8 @@
 // Minimal XML reader for URDF and COLLADA files: elements, attributes, text, comments,
 // processing instructions, self-closing tags. No entities beyond the five predefined ones,
 // no DTDs, no namespaces (prefixes are kept as part of the tag name). Header-only.
+// The files are caller-named: nesting deeper than kMaxDepth is refused (the reader, the tree's destructor and the
+// find helpers recurse per level - a file of 100 000 nested tags used to overflow the stack).
 #pragma once
 #include <cstring>
 #include <memory>
@@ -10,6 +12,8 @@
 #include <vector>
 
 namespace xmlmin {
+
+constexpr int kMaxDepth = 256;   // URDF nests 5 levels, COLLADA about 10
 
 struct Node {
   std::string tag;
@@ -59,7 +63,7 @@ class Parser {
 
   std::unique_ptr<Node> parse() {
     skip_misc();
-    auto root = element();
+    auto root = element(0);
     if (!root) fail("no root element");
     return root;
   }
@@ -108,8 +112,9 @@ class Parser {
     if (p_ == b) fail("expected a name");
     return s_.substr(b, p_ - b);
   }
-  std::unique_ptr<Node> element() {
+  std::unique_ptr<Node> element(int depth) {
     if (p_ >= s_.size() || s_[p_] != '<') return nullptr;
+    if (depth > kMaxDepth) fail("elements nested too deeply");
     p_++;
     auto n = std::make_unique<Node>();
     n->tag = name();
@@ -158,7 +163,7 @@ class Parser {
         n->text = unescape(n->text);
         return n;
       }
-      n->children.push_back(element());
+      n->children.push_back(element(depth + 1));
     }
   }
 };
