@@ -42,6 +42,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_ISSUE_PEAK_GIPS = 256 * 4 * 2.4 / 2.0   # 1228.8 G wave-instructions/s
 EPISODE_STEPS = 1000   # harness time limit (the reference never terminates, trex_env.py:183-184)
 GATHER_JOIN = os.environ.get("TREX_BENCH_GATHER_JOIN", "host")   # "host" | "stream": how the pipelined gather orders step t+2 behind gather t (sharding.PipelinedGather)
+# which exchange the timed region (= `value`) runs for N > 1: "rccl" (default, what the north star names: all_gather_into_tensor,
+# in place, pipelined) or "copy" (sharding.CopyGather: peer copies on a side stream, no collective kernel)
+GATHER_KIND = os.environ.get("TREX_BENCH_GATHER", "rccl")
 EVENT_STRIDE = int(os.environ.get("TREX_BENCH_EVENT_STRIDE", "4"))         # N > 1: HIP-event pairs around every 4th launch of the timed region (see run()); one GPU: ONE spanning pair
 
 
@@ -78,6 +81,54 @@ def _cpu_worker(args):
     return n, time.perf_counter() - t0
 
 
+def _pybullet_worker(args):
+    """BASELINE config 1 with the reference's engine, if the host has it (it has not, on either box of this pool: the leg
+    has never run - it restates the call sites of trex_env.py:98-154 / trex_robot.py:39-65,232-245,397-422 with the
+    build's generated URDF, which carries the 28 collision hulls, and URDF_USE_INERTIA_FROM_FILE):
+    one env, DIRECT client, zero action, 50 warm-up + 1000 timed step() equivalents. Any failure returns None and the
+    caller reports the port's number alone."""
+    try:
+        import numpy as np
+        import pybullet as p
+        urdf, floor = args
+        c = p.connect(p.DIRECT)
+        p.resetSimulation(physicsClientId=c)
+        p.loadURDF(floor, physicsClientId=c)
+        robot = p.loadURDF(urdf, flags=p.URDF_USE_INERTIA_FROM_FILE, physicsClientId=c)
+        p.setPhysicsEngineParameter(numSolverIterations=60, physicsClientId=c)
+        p.setTimeStep(0.002, physicsClientId=c)
+        p.setGravity(0, 0, -9.81, physicsClientId=c)
+        joints = [j for j in range(p.getNumJoints(robot, physicsClientId=c))
+                  if p.getJointInfo(robot, j, physicsClientId=c)[2] == p.JOINT_REVOLUTE]
+        names = [p.getJointInfo(robot, j, physicsClientId=c)[1].decode() for j in joints]
+        joints = [j for _, j in sorted(zip(names, joints))]
+        start = {"joint_femur_left": -0.6, "joint_tibia_left": 0.4, "joint_tarsometatarsus_left": -1.2,
+                 "joint_femur_right": -0.6, "joint_tibia_right": 0.4, "joint_tarsometatarsus_right": -1.2}
+        p.resetBasePositionAndOrientation(robot, [0, 0, 3], [0, 0, 0, 1], physicsClientId=c)
+        for n, j in zip(sorted(names), joints):
+            p.resetJointState(robot, j, start.get(n, 0.0), 0.0, physicsClientId=c)
+        zero = [0.0] * len(joints)
+
+        def step():
+            p.setJointMotorControlArray(robot, joints, p.POSITION_CONTROL, targetPositions=zero,
+                                        positionGains=[5e-3] * len(joints), velocityGains=[0.1] * len(joints),
+                                        forces=[3e5] * len(joints), physicsClientId=c)
+            for _ in range(5):
+                p.stepSimulation(physicsClientId=c)
+            st = p.getJointStates(robot, joints, physicsClientId=c)
+            return np.array([x[0] for x in st] + [x[1] for x in st] + [x[3] for x in st])
+        for _ in range(50):
+            step()
+        t0 = time.perf_counter()
+        for _ in range(1000):
+            step()
+        dt = time.perf_counter() - t0
+        p.disconnect(c)
+        return 1000, dt
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def cpu_baseline(budget_s=10.0):
     import multiprocessing as mp
     # P = the CPUs this job may use: the affinity count (BASELINE.md section 2), limited only by the cgroup's CPU quota
@@ -101,15 +152,31 @@ def cpu_baseline(budget_s=10.0):
     ctx = mp.get_context("spawn")
     with ctx.Pool(cores) as pool:
         one = pool.map(_cpu_worker, [(0, 0.0, "config1")])[0]                       # (i) single core
-        many = pool.map(_cpu_worker, [(i, 0.0, "config1") for i in range(cores)])   # (ii) P processes
+        # (ii) P processes, three repeats: the all-cores figure swings run to run (14 - 22 k on the GPU box's host), so the
+        # line carries the median with the minimum and the maximum
+        many = [pool.map(_cpu_worker, [(i, 0.0, "config1") for i in range(cores)]) for _ in range(3)]
         res = pool.map(_cpu_worker, [(i, budget_s, "random") for i in range(cores)])
+        pb, pb_rates = "unavailable on this host", None
+        try:
+            import importlib.util
+            have_pb = importlib.util.find_spec("pybullet") is not None
+        except Exception:  # noqa: BLE001
+            have_pb = False
+        if have_pb:   # the reference's engine, timed beside the port on the same cores
+            assets = os.path.join(ROOT, "trex-gym_amd", "assets")
+            a = (os.path.join(assets, "trex_collide.urdf"), os.path.join(assets, "floor.urdf"))
+            one_pb = pool.map(_pybullet_worker, [a])[0]
+            many_pb = pool.map(_pybullet_worker, [a] * cores)
+            if one_pb and all(many_pb):
+                pb = "timed"
+                pb_rates = {"single_core_env_steps_per_s": one_pb[0] / one_pb[1],
+                            "all_cores_env_steps_per_s": cores * 1000 / max(t for _, t in many_pb), "processes": cores,
+                            "workload": "BASELINE config 1 with pybullet DIRECT: trex_collide.urdf + URDF_USE_INERTIA_FROM_FILE, zero action"}
+            else:
+                pb = "importable, but the config-1 run failed (see _pybullet_worker)"
     total = sum(n for n, _ in res)
     wall = max(t for _, t in res)
-    try:
-        import pybullet  # noqa: F401
-        pb = "importable (not used: the build's generated URDF cross-check is a later row)"
-    except Exception:  # noqa: BLE001
-        pb = "unavailable on this host"
+    all_cores = sorted(cores * 1000 / max(t for _, t in m) for m in many)
     cpu_model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -125,8 +192,9 @@ def cpu_baseline(budget_s=10.0):
             "config1_zero_action": {
                 "workload": "BASELINE config 1: 1 env per process, zero action, 50 warm-up + 1000 timed steps",
                 "single_core_env_steps_per_s": one[0] / one[1],
-                "all_cores_env_steps_per_s": cores * 1000 / max(t for _, t in many), "processes": cores},
-            "pybullet": pb}
+                "all_cores_env_steps_per_s": all_cores[1], "all_cores_min_max_of_3_repeats": [all_cores[0], all_cores[2]],
+                "processes": cores},
+            "pybullet": pb, **({"pybullet_config1": pb_rates} if pb_rates else {})}
 
 
 def _self_launch(n, argv):
@@ -314,7 +382,7 @@ def main():
     mid, half = 0.5 * (lo + hi), 0.5 * (hi - lo) * args.action_scale
     # a[n, j] ~ U(low_j, high_j), keyed by (seed 0, GLOBAL env id, step), a fresh draw for every step
     # of the run, pre-generated on the device: [T, n, 25] f32 (553 MB at T = 1350, n = 4096)
-    n_blocking = max(10, min(args.steps, 50)) + 5 if world > 1 else 0
+    n_blocking = 2 * (max(10, min(args.steps, 50)) + 5) if world > 1 else 0     # the two other exchange modes, timed after the window
     n_draws = args.action_cycle if args.action_cycle > 0 else args.preroll + args.warmup + args.steps + n_blocking
     pool = torch.empty(n_draws, n_local, len(lo), device=dev)
     for t in range(n_draws):
@@ -329,6 +397,10 @@ def main():
     force_gather = under_launcher and world == 1 and bool(os.environ.get("TREX_BENCH_FORCE_GATHER"))
     pipe = (sharding.PipelinedGather(env.num_envs, env.rows.shape[1], 1, env.rows.dtype, dev) if force_gather else None)
     gather_mode = ["pipelined"]
+    signal_group = None
+    if world > 1 and GATHER_KIND == "copy":
+        # CPU-side group for the copy exchange's handshakes (IPC handles, the per-step barrier): never on the GPU
+        signal_group = dist.new_group(backend="gloo")
 
     host_times = [] if os.environ.get("TREX_BENCH_DUMP_EVENTS") else None   # diagnostic: when the host had enqueued each timed step
 
@@ -372,7 +444,11 @@ def main():
                 elif t == n_steps - 1:
                     span[1].record()
             if world > 1:
-                if gather_mode[0] == "pipelined":
+                if gather_mode[0] == "none":
+                    pass                              # no exchange at all: a policy replica per GPU - the kernel's own scaling
+                elif gather_mode[0] == "pipelined" and GATHER_KIND == "copy":
+                    env.all_gather_rows_copy(signal_group=signal_group, sync=os.environ.get("TREX_BENCH_COPY_SYNC", "barrier"))
+                elif gather_mode[0] == "pipelined":
                     # overlaps the next step; a consumer sees the rows one step late. The block step t+2 rewrites is the one
                     # gather t reads: the HOST waits for gather t here, before it launches step t+2 (a stream wait on the
                     # compute stream costs the chain of step launches 40 % on this ROCm build: scripts/sync_cost_probe.py)
@@ -427,21 +503,28 @@ def main():
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
-    blocking_ms = None
-    if world > 1:   # the blocking form of the exchange, reported beside the pipelined one (not `value`); AFTER the
-        #             timed region: its fences and read-backs would slow the launches that follow them
-        gather_mode[0] = "blocking"
+    blocking_ms = no_exchange_ms = None
+    if world > 1:   # the two other forms, measured in the SAME process right after the timed region (not `value`): no
+        #             exchange at all (replica mode: what the step kernel alone scales like) and the blocking exchange.
+        #             AFTER the window: their fences and read-backs would slow the launches that follow them
         nb = max(10, min(args.steps, 50))
-        tb0 = t_base + args.warmup + args.steps
-        run(5, tb0)
-        fence()
-        tb = time.perf_counter()
-        run(nb, tb0 + 5)
-        fence()
-        blocking_ms = (time.perf_counter() - tb) / nb * 1e3
-        tm_ = torch.tensor([blocking_ms], device=dev, dtype=torch.float64)
-        dist.all_reduce(tm_, op=dist.ReduceOp.MAX)
-        blocking_ms = tm_.item()
+        other = {}
+        for i, mode in enumerate(("none", "blocking")):
+            if env._pipe is not None:
+                env._pipe.flush()
+            if env._copy_pipe is not None:
+                env._copy_pipe.flush()
+            gather_mode[0] = mode
+            tb0 = t_base + args.warmup + args.steps + i * (nb + 5)
+            run(5, tb0)
+            fence()
+            tb = time.perf_counter()
+            run(nb, tb0 + 5)
+            fence()
+            tm_ = torch.tensor([(time.perf_counter() - tb) / nb * 1e3], device=dev, dtype=torch.float64)
+            dist.all_reduce(tm_, op=dist.ReduceOp.MAX)
+            other[mode] = tm_.item()
+        no_exchange_ms, blocking_ms = other["none"], other["blocking"]
         gather_mode[0] = "pipelined"
 
     # dominant kernel: average launch duration over the SAME timed region, from the HIP events
@@ -456,6 +539,12 @@ def main():
               + " | window %.3f ms" % (dt * 1e3), file=sys.stderr)
     if os.environ.get("TREX_BENCH_DUMP_EVENTS") and rank == 0:   # per-launch durations of the timed region (diagnostic)
         print("kernel ms per sampled timed step: " + (" ".join("%.4f" % a.elapsed_time(b) for a, b in sampled) or "(one span event pair)"), file=sys.stderr)
+    kernel_ms_ranks = [kernel_ms]
+    if world > 1:   # the step launch's average duration on every rank: min / max separate "the kernel scales" from "the exchange costs"
+        km = torch.zeros(world, device=dev, dtype=torch.float64)
+        km[rank] = kernel_ms
+        dist.all_reduce(km)
+        kernel_ms_ranks = km.tolist()
     finite = bool(torch.isfinite(many_rows if S > 1 else env.obs).all().item())
     info = env.batch.launch_info()
     build_id = _capi.build_id()
@@ -529,8 +618,20 @@ def main():
             "outputs_finite": finite,
         }
         if blocking_ms is not None:
-            out["gather"] = {"pipelined_ms_per_step": dt / args.steps * 1e3, "blocking_ms_per_step": blocking_ms,
+            out["gather"] = {"no_exchange_ms_per_step": no_exchange_ms, "pipelined_ms_per_step": dt / args.steps * 1e3,
+                             "blocking_ms_per_step": blocking_ms,
+                             "kind": ("peer copies on a side stream (sharding.CopyGather), sync=%s" % os.environ.get("TREX_BENCH_COPY_SYNC", "barrier"))
+                                     if GATHER_KIND == "copy" else "all_gather_into_tensor (%s), in place" % dist.get_backend(),
+                             "join": GATHER_JOIN if GATHER_KIND != "copy" else "host (event query)",
+                             "kernel_ms_min_over_ranks": min(kernel_ms_ranks), "kernel_ms_max_over_ranks": max(kernel_ms_ranks),
+                             "note": "value = the pipelined form (gathered rows are one step old); no_exchange = the same steps with no "
+                                     "exchange at all (a policy replica per GPU, SURVEY 8e): the step kernel's own scaling; blocking = the "
+                                     "consumer sees this step's rows. All three timed in this process, max over ranks",
                              "row_block": "[n, 3J+2] f32 = obs | reward | done"}
+        # rehearsal / diagnostic switches that were set: a leaked variable must not change the number silently
+        switches = {k: v for k, v in sorted(os.environ.items()) if k.startswith("TREX_") and k != "TREX_BENCH_SELF_LAUNCHED"}
+        if switches:
+            out["env_switches"] = switches
         if cpu is not None:
             out["cpu_baseline"] = cpu
         _emit(json.dumps(out))

@@ -39,8 +39,15 @@ def _rank(rank, world, port, ret):
         got.append(None if prev is None else prev.clone().cpu())
     got.append(env._pipe.flush().clone().cpu())
     blocking = env.all_gather_rows().clone().cpu()              # the blocking form: this step's rows
+    # the same exchange by peer copies (sharding.CopyGather: IPC-mapped buffers, copy engines, no collective kernel)
+    got_copy = []
+    for t in range(STEPS, STEPS + 5):
+        env.step_tensor(_actions(env.model.lower, env.model.upper, ids, t, dev))
+        prev = env.all_gather_rows_copy()
+        got_copy.append(None if prev is None else prev.clone().cpu())
+    got_copy.append(env._copy_pipe.flush().clone().cpu())
     if rank == 1:
-        ret["got"], ret["blocking"] = got, blocking
+        ret["got"], ret["blocking"], ret["got_copy"] = got, blocking, got_copy
     dist.barrier()
     dist.destroy_process_group()
 
@@ -58,12 +65,16 @@ def test_two_ranks_on_the_gpu_gather_what_one_process_computes():
     ref.reset_tensor()
     ids = torch.arange(N_GLOBAL, device=dev)
     rows = []
-    for t in range(STEPS):
+    for t in range(STEPS + 5):
         ref.step_tensor(_actions(ref.model.lower, ref.model.upper, ids, t, dev))
         rows.append(ref.rows.clone().cpu())
     got = ret["got"]
     assert got[0] is None
     for t in range(1, STEPS + 1):                 # call t returns the rows of step t - 1, of BOTH shards
         assert torch.equal(got[t], rows[t - 1]), t
-    assert torch.equal(ret["blocking"], rows[-1])
+    assert torch.equal(ret["blocking"], rows[STEPS - 1])
+    gc = ret["got_copy"]
+    assert gc[0] is None
+    for i in range(1, 6):                         # copy exchange: call i returns the rows of its previous step
+        assert torch.equal(gc[i], rows[STEPS + i - 1]), i
     assert float(rows[3][:, 76].sum()) == N_GLOBAL     # the episode limit fired inside the launches, on every env

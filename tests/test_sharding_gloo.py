@@ -250,3 +250,35 @@ def test_in_place_gather_with_the_host_join_orders_the_same_without_a_stream_wai
         i_gather = next(i for i, e in enumerate(log) if e[0] == "gather" and e[1] == t - 2)
         done = [i for i, e in enumerate(log) if e == ("hostwait", t - 2)]
         assert done and i_gather < min(done) < i_write, (t, log)
+
+
+def test_host_join_raises_on_a_failed_gather_and_on_a_stalled_peer(monkeypatch):
+    """`is_completed()` of a c10d work also turns true once an exception is set, and the host join used to
+    spin on it without a deadline. A gather that completed WITH an error must raise (not hand out rows that never
+    arrived, not let step t+2 overwrite the block), and a peer that never arrives must end in TimeoutError."""
+    from trex_gym import sharding
+
+    class _Failed:
+        def is_completed(self):
+            return True
+
+        def is_success(self):
+            return False
+
+    class _Stalled:
+        def is_completed(self):
+            return False
+
+        def is_success(self):
+            return True
+
+    works = []
+    monkeypatch.setattr(sharding.dist, "all_gather_into_tensor", lambda out, src, group=None, async_op=False: works.pop(0))
+    blocks = [torch.zeros(3, 5), torch.zeros(3, 5)]
+    for bad, err in ((_Failed(), RuntimeError), (_Stalled(), TimeoutError)):
+        monkeypatch.setattr(sharding.PipelinedGather, "HOST_JOIN_TIMEOUT_S", 0.05)
+        pipe = sharding.PipelinedGather(3, 5, 2, torch.float32, "cpu")
+        works[:] = [bad, _FakeWork([], 1)]
+        assert pipe.push(blocks[0], copy=False, wait=False, join="host") is None
+        with pytest.raises(err):
+            pipe.push(blocks[1], copy=False, wait=False, join="host")      # must join gather 0 before step 2 may be enqueued

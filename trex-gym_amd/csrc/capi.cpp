@@ -42,8 +42,8 @@ struct TrexBatch {
   TrexDeviceModel *dmodel = nullptr;
   TrexBatchArrays arr{};
   float wd = 1.0f, we = 0.005f, wk = 0.002f;  // trex_env.py:42-44
-  int balance_mode = -1;                       // trex_batch_set_wave_balance: -1 auto, 0 off, 1 on
-  bool balance() const { return balance_mode < 0 ? n >= 2048 : balance_mode != 0; }
+  int balance_mode = -1;                       // trex_batch_set_wave_balance: -1 auto, 0 off, 1 on, 2 on without the persistent launch
+  int balance() const { return balance_mode < 0 ? (n >= 2048 ? 1 : 0) : balance_mode; }
   std::vector<void *> allocs;
   // caller allocations already validated as memory of this device (base address, bytes known to be good):
   // the hot path pays one hash-free scan of a handful of entries, hipPointerGetAttributes only on a new one
@@ -401,7 +401,6 @@ int trex_batch_create(const TrexModel *model, int num_envs, int device, TrexBatc
   A(n * 16 * sizeof(float), (void **)&b->arr.base);
   A(n * TREX_TL * sizeof(float), (void **)&b->arr.q);
   A(n * TREX_TL * sizeof(float), (void **)&b->arr.qd);
-  A(n * TREX_TL * sizeof(float), (void **)&b->arr.tau);
   A(n * TREX_TL * sizeof(float), (void **)&b->arr.mass_scale);
   A(n * sizeof(float), (void **)&b->arr.friction);
   A(TREX_BAL_WORDS(n) * sizeof(int32_t), (void **)&b->arr.balance);
@@ -480,7 +479,7 @@ int trex_batch_set_reward_weights(TrexBatch *b, float distance, float energy, fl
 
 int trex_batch_set_wave_balance(TrexBatch *b, int mode) {
   if (check_batch(b)) return TREX_E_INVALID;
-  if (mode < -1 || mode > 1) return fail(TREX_E_INVALID, "trex_batch_set_wave_balance: mode must be -1 (auto), 0 (off) or 1 (on)");
+  if (mode < -1 || mode > 2) return fail(TREX_E_INVALID, "trex_batch_set_wave_balance: mode must be -1 (auto), 0 (off), 1 (on) or 2 (on, one workgroup per env)");
   b->balance_mode = mode;
   return TREX_OK;
 }
@@ -609,7 +608,6 @@ int trex_batch_set_state(TrexBatch *b, const float *state_dev, void *stream) {
   DeviceGuard guard(b->device);
   BUF_TRY(state_dev, (size_t)b->n * (13 + 2 * b->nj) * sizeof(float), "trex_batch_set_state: state");
   HIP_TRY(trex_launch_pack_state(b->dmodel, b->arr, b->n, const_cast<float *>(state_dev), 0, (hipStream_t)stream));
-  HIP_TRY(trex_launch_fill(b->arr.tau, 0.0f, b->n * TREX_TL, (hipStream_t)stream));
   return TREX_OK;
 }
 int trex_batch_set_motors_enabled(TrexBatch *b, int enabled, void *stream) {

@@ -49,7 +49,8 @@ struct TrexDeviceModel {
  *                  reset, as an int (the harness's episode limit). ONE 64-byte line carries everything the step launch
  *                  reads and writes per env besides the joint rows (round 2 kept the four scalars in arrays of their
  *                  own: four more partial-line reads and writes per env-step).
- *   q, qd, tau  [N][32]  indexed by BODY lane (lane 0 unused)
+ *   q, qd  [N][32]  indexed by BODY lane (lane 0 unused). (The last motor torques are NOT kept: they are an output - the
+ *                  observation's third block - and no step reads them back.)
  *   mass_scale [N][32], friction [N]: domain randomisation; read only when `domain` is set (trex_batch_set_domain) */
 #define TREX_BASE_FLAGS 13
 #define TREX_BASE_IMPULSE 14
@@ -57,17 +58,21 @@ struct TrexDeviceModel {
 #define TREX_MOTORS_BIT 256
 #define TREX_BAL_PHASE 0
 #define TREX_BAL_FINISHED 1
+#define TREX_BAL_CURSOR 2      /* persistent launch (more envs than wave slots): next rank to draw */
+#define TREX_BAL_EXITED 3      /* persistent launch: workgroups that have left it */
+#define TREX_WAVE_SLOTS 4096   /* 256 CUs x 4 SIMDs x 4 waves of 128 registers */
 #define TREX_BAL_COUNTS 16
 #define TREX_BAL_BINS 16
 #define TREX_BAL_LISTS 48
 #define TREX_BAL_WORDS(n) (TREX_BAL_LISTS + 2 * TREX_BAL_BINS * (size_t)(n))
 
 struct TrexBatchArrays {
-  float *base, *q, *qd, *tau, *mass_scale, *friction;
+  float *base, *q, *qd, *mass_scale, *friction;
   int32_t domain;         /* != 0: per-env mass_scale / friction are in force (else the model's values: no loads) */
   int32_t pad0_;
   int32_t *balance;       /* wave balance, device-side state only: [TREX_BAL_PHASE] which of the two list sets the next
                              step launch reads, [TREX_BAL_FINISHED] waves of the running launch that have ended,
+                             [TREX_BAL_CURSOR], [TREX_BAL_EXITED] the persistent launch's rank cursor and exit count,
                              [TREX_BAL_COUNTS + 16 p + c] envs filed under contact count c in set p,
                              [TREX_BAL_LISTS + (16 p + c) N + i] the i-th of them */
   int32_t max_episode_steps;  /* 0 = no limit; > 0: an env whose count reaches it is reset INSIDE the step launch */

@@ -72,7 +72,7 @@
     __builtin_amdgcn_sched_barrier(0);                                                    \
     const unsigned long long _t = __builtin_amdgcn_s_memtime();                           \
     __builtin_amdgcn_s_waitcnt(0xC07F);                                                   \
-    if (args.debug && threadIdx.x == 0) args.debug[4096 + (i) * args.n_envs + blockIdx.x] += (float)(_t - stamp_last); \
+    if (args.debug && threadIdx.x == 0) args.debug[4096 + (i) * args.n_envs + wg] += (float)(_t - stamp_last); \
     stamp_last = _t;                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                    \
   } while (0)
@@ -328,7 +328,7 @@ struct WaveLds {
   union {
     float aba[32][28];        // tip-to-base pass: articulated inertia (21) + bias force (6) per body      3584 B
     float4 desc[64][4];       // B build: column descriptor of the row on lane L: chain | zc[6] | z0[6]     4096 B
-    float jcol[NJMAX][64];    // sweeps: [j-1][row lane] = B entries of motor column j (limit rows)        6400 B
+    float4 cg[336];           // contact generation: CgLds (below)                                          5376 B
   } u;
   float cpt[MAXC][8];         // contact points: body, x, y, z (rel. base origin), distance     416 B
   float st[6][TL];            // per body lane, parked across the phases: q, qd, motor torque, target, updated rate, 1/M^-1_jj  768 B
@@ -373,8 +373,11 @@ struct KernelArgs {
 // MULTI: the launch advances every env by args.n_steps env-steps (open-loop action sequences): the state stays in
 // SGPRs / LDS between the steps and - what it is for - no wave ever waits for the slowest wave of a step: with one step
 // per launch the SIMDs idle a fifth of the launch behind its heaviest envs.
-template <bool RESET, bool DEBUG, bool MULTI>
-__device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
+// PERSIST (batches of more than 4096 envs, trex_step_persist_kernel): the launch has as many workgroups as the chip has wave
+// slots and every workgroup takes env after env off the rank lists, heaviest class first (k = the rank it drew), instead
+// of one workgroup per env in workgroup order.
+template <bool RESET, bool DEBUG, bool MULTI, bool PERSIST = false>
+__device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int wg) {   // wg: blockIdx.x, or the rank drawn
   __shared__ WaveLds W;
   const int tid = threadIdx.x;
   const TrexDeviceModel *__restrict__ M = args.model;
@@ -385,14 +388,14 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
   // (workgroups j, 1024 + j, ...) gets the j-th heaviest env together with the j-th lightest of each later block -
   // the sums of work per SIMD are level. Device-side state only (phase, counts, lists): nothing to launch before
   // the step, and a captured graph replays correctly.
-  int env = blockIdx.x;
+  int env = wg;
   int bal_phase = 0;
   if (args.bal) {
     const int32_t *B = args.bal;
     bal_phase = uni(B[TREX_BAL_PHASE]);
     const int32_t *cnt = B + TREX_BAL_COUNTS + TREX_BAL_BINS * bal_phase;
-    const int k = (int)blockIdx.x, q = k >> 10, m = min(1024, args.n_envs - (q << 10));
-    int r = q == 0 ? k : (q << 10) + (m - 1 - (k & 1023));
+    const int k = wg, q = k >> 10, m = min(1024, args.n_envs - (q << 10));
+    int r = (PERSIST || q == 0) ? k : (q << 10) + (m - 1 - (k & 1023));   // (PERSIST: ranks are drawn in order, heaviest first)
     // (not better, measured: SIMD j taking rank j and the 3 LIGHTEST envs still to be dealt - 11.07 M against 11.13 M
     // at 4096 envs, 13.02 M against 13.18 M at 32768: which light mates a heavy wave has does not matter)
     const int lane_ = (int)threadIdx.x;
@@ -411,7 +414,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
     // still file their envs below, so the next launch finds sound lists again.
     if (total == args.n_envs) {
       env = B[TREX_BAL_LISTS + (size_t)(bal_phase * TREX_BAL_BINS + b) * args.n_envs + r];
-      if (env < 0 || env >= args.n_envs) env = blockIdx.x;   // (unreachable with sound lists; never an out-of-range row)
+      if (env < 0 || env >= args.n_envs) env = wg;   // (unreachable with sound lists; never an out-of-range row)
     }
   }
   env = uni(env);
@@ -442,12 +445,14 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
   if (RESET && !do_reset) {
     // an env that is not reset only hands out its observation again: no physics, no kinematics, no LDS. (The
     // episode-limit reset of a VecEnv runs with a mask every step: about N/1000 envs reset, the rest end here.)
+    // Its motor-torque columns are LEFT as the caller's row holds them - the last step wrote them there; the batch keeps no
+    // copy of its own (until round 3 a [N][32] row, written by every step and read only here: 0.5 MB of the 3.7 MB a
+    // 4096-env step launch wrote).
     if (args.obs && tid >= 1 && tid < nb) {
       float *o = args.obs + (size_t)env * args.obs_stride;
       const int slot = M->obs_slot[tid];
       o[slot] = args.arr.q[(size_t)env * TL + tid];
       o[nj + slot] = args.arr.qd[(size_t)env * TL + tid];
-      o[2 * nj + slot] = args.arr.tau[(size_t)env * TL + tid];
     }
     return;
   }
@@ -513,8 +518,8 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
 #define TREX_PRIO_T2 3
 #define TREX_PRIO_T3 6
 #endif
-  const bool aged_launch = args.n_envs <= 4096;
-  const int wave_pair = ((int)blockIdx.x >> 11) & 1;      // 0: the two older waves of the SIMD, 1: the two younger
+  const bool aged_launch = !PERSIST && args.n_envs <= 4096;
+  const int wave_pair = (wg >> 11) & 1;      // 0: the two older waves of the SIMD, 1: the two younger
   auto set_sweep_priority = [&](int contacts) {
     int v = contacts >= TREX_PRIO_T3 ? 3 : (contacts >= TREX_PRIO_T2 ? 2 : (contacts >= TREX_PRIO_T1 ? 1 : 0));
     v += (aged_launch && wave_pair == 1) ? 1 : 0;
@@ -588,7 +593,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
 #if TREX_STAMPS
   unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
   int stamp_alive = 0, stamp_lamnz = 0;
-  if (args.debug && threadIdx.x == 0) args.debug[4096 + 11 * args.n_envs + blockIdx.x] = (float)env;   // the env of this wave
+  if (args.debug && threadIdx.x == 0) args.debug[4096 + 11 * args.n_envs + wg] = (float)env;   // the env of this wave
 #endif
   // Episode limit of the harness (the reference never terminates, trex_env.py:183-184; a VecEnv auto-resets): the env
   // whose count reaches the limit with this step finishes the step - reward, done = 1 - and then, IN THE SAME LAUNCH,
@@ -1341,7 +1346,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
         reinterpret_cast<float *>(&W.body[BREC * lt + 1])[3] = nqd;
         W.st[ST_NQD][lt] = nqd;
       }
-      if (DEBUG && args.debug && blockIdx.x == 0) {
+      if (DEBUG && args.debug && wg == 0) {
         float *D = args.debug;
         if (lt < TL) { D[lt] = qdd; D[64 + lt] = nqd; }
 #pragma unroll
@@ -1545,12 +1550,8 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    __syncthreads();   // every lane is done with the descriptors: the limit rows' columns may take their place
-    if (lim_mask != 0u || DEBUG) {   // the dynamically indexed limit rows read their column from LDS
-#pragma unroll
-      for (int j = 1; j <= NJMAX; j++) W.u.jcol[j - 1][lt] = Bm[j - 1];
-    }
-    __syncthreads();
+    // (the descriptors stay where they are. Until round 3 the limit rows read their B column from LDS - 25 columns staged
+    // over the descriptors, 6400 B, whenever a joint sat on a stop; they now take it from the lane's own Bm register)
     STAMP(6);
     RELANE();
 
@@ -1651,7 +1652,74 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
           const float dl = (nl - lim_lam) * ldir;
           if (vs == j) lim_lam = nl;
           const float sd = rl(dl, j);
-          y += W.u.jcol[j - 1][lt] * sd;
+          // column j of B sits in register Bm[j - 1] of every lane and j is wave-uniform: a computed jump into a table of
+          // (v_fmac, s_branch) pairs, 8 bytes each - five scalar instructions and ONE v_fmac per limit-row visit. (As a C
+          // switch the compiler lowered this to ~30 flag tests per visit; until round 3 the column came from LDS, where
+          // all 25 were staged over the row descriptors - 6400 B - whenever a joint sat on a stop.) s_getpc yields the
+          // address of the instruction that follows it; the four instructions up to and including s_setpc are 16
+          // bytes, so entry j (1-based) sits at pc + 16 + 8 (j - 1) = pc + 8 j + 8.
+          {
+            int jt_;
+            static_assert(NJMAX == 25, "the jump table below has 25 entries");
+            asm volatile("s_getpc_b64 s[100:101]\n\t"
+                         "s_lshl3_add_u32 %[t], %[j], 8\n\t"
+                         "s_add_u32 s100, s100, %[t]\n\t"
+                         "s_addc_u32 s101, s101, 0\n\t"
+                         "s_setpc_b64 s[100:101]\n\t"
+                         "v_fmac_f32_e32 %[y], %[sd], %[b1]\n\t"
+                         "s_branch 9f\n\t"
+                         "v_fmac_f32_e32 %[y], %[sd], %[b2]\n\t"
+                         "s_branch 9f\n\t"
+                         "v_fmac_f32_e32 %[y], %[sd], %[b3]\n\t"
+                         "s_branch 9f\n\t"
+                         "v_fmac_f32_e32 %[y], %[sd], %[b4]\n\t"
+                         "s_branch 9f\n\t"
+                         "v_fmac_f32_e32 %[y], %[sd], %[b5]\n\t"
+                         "s_branch 9f\n\t"
+                         "v_fmac_f32_e32 %[y], %[sd], %[b6]\n\t"
+                         "s_branch 9f\n\t"
+                         "v_fmac_f32_e32 %[y], %[sd], %[b7]\n\t"
+                         "s_branch 9f\n\t"
+                         "v_fmac_f32_e32 %[y], %[sd], %[b8]\n\t"
+                         "s_branch 9f\n\t"
+                         "v_fmac_f32_e32 %[y], %[sd], %[b9]\n\t"
+                         "s_branch 9f\n\t"
+                         "v_fmac_f32_e32 %[y], %[sd], %[b10]\n\t"
+                         "s_branch 9f\n\t"
+                         "v_fmac_f32_e32 %[y], %[sd], %[b11]\n\t"
+                         "s_branch 9f\n\t"
+                         "v_fmac_f32_e32 %[y], %[sd], %[b12]\n\t"
+                         "s_branch 9f\n\t"
+                         "v_fmac_f32_e32 %[y], %[sd], %[b13]\n\t"
+                         "s_branch 9f\n\t"
+                         "v_fmac_f32_e32 %[y], %[sd], %[b14]\n\t"
+                         "s_branch 9f\n\t"
+                         "v_fmac_f32_e32 %[y], %[sd], %[b15]\n\t"
+                         "s_branch 9f\n\t"
+                         "v_fmac_f32_e32 %[y], %[sd], %[b16]\n\t"
+                         "s_branch 9f\n\t"
+                         "v_fmac_f32_e32 %[y], %[sd], %[b17]\n\t"
+                         "s_branch 9f\n\t"
+                         "v_fmac_f32_e32 %[y], %[sd], %[b18]\n\t"
+                         "s_branch 9f\n\t"
+                         "v_fmac_f32_e32 %[y], %[sd], %[b19]\n\t"
+                         "s_branch 9f\n\t"
+                         "v_fmac_f32_e32 %[y], %[sd], %[b20]\n\t"
+                         "s_branch 9f\n\t"
+                         "v_fmac_f32_e32 %[y], %[sd], %[b21]\n\t"
+                         "s_branch 9f\n\t"
+                         "v_fmac_f32_e32 %[y], %[sd], %[b22]\n\t"
+                         "s_branch 9f\n\t"
+                         "v_fmac_f32_e32 %[y], %[sd], %[b23]\n\t"
+                         "s_branch 9f\n\t"
+                         "v_fmac_f32_e32 %[y], %[sd], %[b24]\n\t"
+                         "s_branch 9f\n\t"
+                         "v_fmac_f32_e32 %[y], %[sd], %[b25]\n\t"
+                         "9:\n\t"
+                         : [y] "+v"(y), [t] "=&s"(jt_)
+                         : [sd] "s"(sd), [j] "s"(j), [b1] "v"(Bm[0]), [b2] "v"(Bm[1]), [b3] "v"(Bm[2]), [b4] "v"(Bm[3]), [b5] "v"(Bm[4]), [b6] "v"(Bm[5]), [b7] "v"(Bm[6]), [b8] "v"(Bm[7]), [b9] "v"(Bm[8]), [b10] "v"(Bm[9]), [b11] "v"(Bm[10]), [b12] "v"(Bm[11]), [b13] "v"(Bm[12]), [b14] "v"(Bm[13]), [b15] "v"(Bm[14]), [b16] "v"(Bm[15]), [b17] "v"(Bm[16]), [b18] "v"(Bm[17]), [b19] "v"(Bm[18]), [b20] "v"(Bm[19]), [b21] "v"(Bm[20]), [b22] "v"(Bm[21]), [b23] "v"(Bm[22]), [b24] "v"(Bm[23]), [b25] "v"(Bm[24])
+                         : "s100", "s101", "scc");
+          }
         }
         // motor rows (joints beyond nb are null rows: y = 0, bounds 0), hand-placed: 5 issue slots per row (the compiler's
         // form of TREX_ROW takes 8). With the bounds SHIFTED by the impulse, d_j = clamp(lam_j + y_j) - lam_j =
@@ -1873,7 +1941,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
     const float mdg = W.st[ST_MDG][bl];
     const float dv = mrow ? dvj * mdg : 0.f;
 
-    if (DEBUG && args.debug && blockIdx.x == 0) {
+    if (DEBUG && args.debug && wg == 0) {
       float *D = args.debug;
       if (lt < TL) D[96 + lt] = dv;
       if (lt == 0) {
@@ -1883,7 +1951,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
       // joint block of M^-1 recovered from the staged columns, contact points and their impulses
       if (lt < TL) {
 #pragma unroll
-        for (int j = 1; j <= NJMAX; j++) D[160 + 32 * (j - 1) + lt] = mrow ? -W.u.jcol[j - 1][lt] * mdg : 0.f;
+        for (int j = 1; j <= NJMAX; j++) D[160 + 32 * (j - 1) + lt] = mrow ? -Bm[j - 1] * mdg : 0.f;
       }
       for (int c = 0; c < nc; c++) {
         const float l0 = rl(lam, krow_lane(3 * (s0 + c))), l1 = rl(lam, krow_lane(3 * (s0 + c) + 1)), l2 = rl(lam, krow_lane(3 * (s0 + c) + 2));
@@ -1943,8 +2011,8 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
 
 #if TREX_STAMPS
   if (args.debug && threadIdx.x == 0) {
-    args.debug[4096 + 14 * args.n_envs + blockIdx.x] = (float)stamp_alive;
-    args.debug[4096 + 15 * args.n_envs + blockIdx.x] = (float)stamp_lamnz;
+    args.debug[4096 + 14 * args.n_envs + wg] = (float)stamp_alive;
+    args.debug[4096 + 15 * args.n_envs + wg] = (float)stamp_lamnz;
   }
 #endif
   // ---- end of the env-step: outputs
@@ -1987,8 +2055,8 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
   // ---- epilogue: the state goes back to HBM
   const int lt = lane_id();
   const int bl = lt & (TL - 1);
-  float q = W.st[ST_Q][bl], qd = W.st[ST_QD][bl], mtau = W.st[ST_TAU][bl];
-  if (lt >= TL) { q = 0.f; qd = 0.f; mtau = 0.f; }
+  float q = W.st[ST_Q][bl], qd = W.st[ST_QD][bl];
+  if (lt >= TL) { q = 0.f; qd = 0.f; }
   const bool store_state = RESET ? do_reset : true;
   if (store_state) {
     // base row: pos(3) quat(4) v(3) w(3); lane k < 13 stores word k (static selects: a dynamically indexed
@@ -2004,7 +2072,6 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
     if (lt < TL) {
       args.arr.q[(size_t)env * TL + lt] = q;
       args.arr.qd[(size_t)env * TL + lt] = qd;
-      args.arr.tau[(size_t)env * TL + lt] = mtau;
     }
   }
   if (lt == 0) {
@@ -2022,7 +2089,8 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
       if (at < args.n_envs) B[TREX_BAL_LISTS + (size_t)(w * TREX_BAL_BINS + bin) * args.n_envs + at] = env;
       // (no fence: the lists are read by the NEXT launch only; within this launch the last wave needs nothing but
       // the count of ended waves, an atomic)
-      if (atomicAdd(&B[TREX_BAL_FINISHED], 1) == args.n_envs - 1) {
+      // (PERSIST: the last WORKGROUP to leave the launch does this, trex_step_persist_kernel)
+      if (!PERSIST && atomicAdd(&B[TREX_BAL_FINISHED], 1) == args.n_envs - 1) {
         B[TREX_BAL_FINISHED] = 0;
         for (int i = 0; i < TREX_BAL_BINS; i++) B[TREX_BAL_COUNTS + TREX_BAL_BINS * bal_phase + i] = 0;
         B[TREX_BAL_PHASE] = w;
@@ -2032,9 +2100,42 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args) {
 }
 
 template <bool RESET, bool DEBUG>
-__global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) { trex_step_body<RESET, DEBUG, false>(args); }
+__global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) { trex_step_body<RESET, DEBUG, false>(args, (int)blockIdx.x); }
 // S env-steps per launch (trex_batch_step_many)
-__global__ __launch_bounds__(64, 4) void trex_step_many_kernel(KernelArgs args) { trex_step_body<false, false, true>(args); }
+__global__ __launch_bounds__(64, 4) void trex_step_many_kernel(KernelArgs args) { trex_step_body<false, false, true>(args, (int)blockIdx.x); }
+// More envs than the chip has wave slots (4096 = 256 CUs x 16): a launch of one workgroup per env is refilled by the
+// dispatcher in workgroup order as slots fall free, and ends with a tail of whatever envs came last - 8192 envs stepped at
+// 11.5 M env-steps/s where two free-running batches of 4096 reach 14.0 M (profiles/r03_group_pipeline.txt). Here the grid
+// IS the wave slots, and every workgroup draws rank after rank from one atomic cursor: the heaviest contact class first,
+// the lightest envs last (longest-processing-time-first: the tail is as short as the lightest env), no slot ever waits for
+// the dispatcher. Which workgroup steps which env changes nothing in the results (one env per wave, no shared state:
+// tests/test_gpu_parity.py::test_rank_lists_cover_every_env_at_ragged_sizes). Device-side state only: the cursor is
+// zeroed by the last workgroup to leave - every workgroup has drawn its final, failing rank by then -, which also clears
+// the counts the launch read and flips the list phase; a captured graph replays correctly.
+__global__ __launch_bounds__(64, 4) void trex_step_persist_kernel(KernelArgs args) {
+  int32_t *B = args.arr.balance;
+  // first env of every workgroup: dealt like a resident launch of TREX_WAVE_SLOTS envs (workgroup b sits on SIMD b mod
+  // 1024: ranks 0..1023 in order, every later block of 1024 in reverse - the sums of work per SIMD are level; drawn in
+  // workgroup order instead, SIMD 0 gets the heaviest env of every block: 10.1 M against 11.4 M env-steps/s at 8192 envs)
+  const int b = (int)blockIdx.x, q = b >> 10;
+  int k = q == 0 ? b : (q << 10) + (1023 - (b & 1023));     // (the launcher guarantees n_envs > TREX_WAVE_SLOTS = gridDim.x)
+  for (;;) {   // ... then rank after rank off the cursor, heaviest first
+    trex_step_body<false, false, false, true>(args, k);
+    k = 0;
+    if (threadIdx.x == 0) k = TREX_WAVE_SLOTS + atomicAdd(&B[TREX_BAL_CURSOR], 1);
+    k = uni(k);
+    if (k >= args.n_envs) break;
+  }
+  if (threadIdx.x == 0 && atomicAdd(&B[TREX_BAL_EXITED], 1) == (int)gridDim.x - 1) {
+    B[TREX_BAL_EXITED] = 0;
+    B[TREX_BAL_CURSOR] = 0;
+    if (args.bal) {
+      const int p = B[TREX_BAL_PHASE];
+      for (int i = 0; i < TREX_BAL_BINS; i++) B[TREX_BAL_COUNTS + TREX_BAL_BINS * p + i] = 0;
+      B[TREX_BAL_PHASE] = p ^ 1;
+    }
+  }
+}
 
 // ---------------------------------------------------------------- small utility kernels
 __global__ void trex_pack_state_kernel(const TrexDeviceModel *M, TrexBatchArrays arr, int n, float *out, int pack) {
@@ -2208,9 +2309,14 @@ hipError_t trex_launch_step(const TrexDeviceModel *model, TrexBatchArrays arr, i
                             int balance, int pen_in_rows) {
   // balance: the env-to-wave assignment by contact rank (trex_batch_set_wave_balance decides; capi.cpp). Diagnostics
   // launches keep env k in workgroup k (the stamped build is balanced like the product: it reports the env of every wave)
+  // balance: 0 off, 1 lists (+ the persistent launch beyond 4096 envs), 2 lists with one workgroup per env at any size
   int32_t *perm = ((debug && !TREX_STAMPS) || !balance) ? nullptr : arr.balance;
   KernelArgs a{model, arr, n, actions, obs, reward, done, done_f, obs_stride, scal_stride, penalties, nullptr, perm, wd, we, wk, debug,
                1, 0, pen_in_rows};
+  if (balance == 1 && !debug && !TREX_STAMPS && n > TREX_WAVE_SLOTS) {
+    hipLaunchKernelGGL(trex_step_persist_kernel, dim3(TREX_WAVE_SLOTS), dim3(64), 0, stream, a);
+    return hipGetLastError();
+  }
 #if TREX_STAMPS   // diagnostic build: the PRODUCT instantiation, stamped (the dump of <false, true> would change its code)
   hipLaunchKernelGGL((trex_step_kernel<false, false>), dim3(n), dim3(64), 0, stream, a);
 #else

@@ -116,10 +116,32 @@ class PipelinedGather:
         self.work = [None, None]
         self.k = 0
 
-    @staticmethod
-    def _host_wait(work):
-        while not work.is_completed():       # (an event query; the gather it waits for ended a step launch ago)
+    HOST_JOIN_TIMEOUT_S = 120.0     # a gather takes microseconds; a peer that never arrives must not hang the loop for ever
+
+    @classmethod
+    def _host_wait(cls, work):
+        """Spin on the work handle's completion query (an event query; the gather it waits for ended a step launch ago)
+        - with a deadline, and treating a work that completed WITH AN ERROR as an error: `is_completed()` of a c10d work
+        also turns true once an exception is set, and a failed or aborted gather must not hand out (or let the next step
+        overwrite) rows that never arrived."""
+        t0 = None
+        while not work.is_completed():
+            now = time.monotonic()
+            if t0 is None:
+                t0 = now
+            elif now - t0 > cls.HOST_JOIN_TIMEOUT_S:
+                raise TimeoutError("PipelinedGather: the all-gather did not complete within %.0f s (a peer rank is stalled or gone)"
+                                   % cls.HOST_JOIN_TIMEOUT_S)
             time.sleep(0)
+        # (Work.exception() cannot be converted to Python on this torch build - "Unregistered type exception_ptr";
+        # is_success() is the query that works: gloo implements it, ProcessGroupNCCL may refuse it - there the watchdog
+        # aborts the process on an asynchronous error, so a refusal to answer is not taken as a failure)
+        try:
+            ok = bool(work.is_success())
+        except Exception:  # noqa: BLE001
+            ok = True
+        if not ok:
+            raise RuntimeError("PipelinedGather: the all-gather completed with an error (peer failure or aborted communicator)")
 
     def push(self, local, copy=True, wait=True, join="stream"):
         """Launch the gather of `local`; returns the previous call's gathered rows (None on the first).
@@ -161,3 +183,86 @@ class PipelinedGather:
                 self.work[k].wait()
                 last = self.out[k]
         return last
+
+
+class CopyGather:
+    """The same exchange WITHOUT a collective kernel: every rank copies its row block straight into every peer's
+    gathered buffer (peer memory mapped through HIP IPC; xGMI is point-to-point, so an all-gather IS world-1 peer
+    writes per rank) with plain device-to-device copies on a side stream - copy-engine work, no workgroup beside the
+    step launch. Why: the step launch of 4096 envs holds every CU's wave slots and most of its LDS; a collective
+    KERNEL on another hardware queue slowed the step launches by 9 - 14 % in the one-GPU rehearsals with RCCL
+    (DESIGN.md 7), a device-to-device copy on a side stream by 1.6 - 1.9 % (scripts/overlap_probe.py). RCCL stays the
+    default the north star names; this is the variant `bench.py` runs under TREX_BENCH_GATHER=copy.
+
+    In-place, pipelined like PipelinedGather(copy=False): the producer alternates between two row blocks and calls
+    push() after every step; push(t) returns the rows of step t-1 (None on the first call).
+      * producer side: the copies of step t read block t & 1 while step t+1 fills the other; step t+2 rewrites it, so
+        push(t+1) returns only when the HOST has seen the copies of step t complete (an event query - no wait on the
+        stream that carries the step launches, same reasoning as PipelinedGather's host join);
+      * across ranks: a rank's out[k] holds step t of EVERY rank once every rank's copies of step t are complete.
+        sync="barrier": push(t+1) then passes a barrier of `signal_group` (a CPU-side gloo group; the GPU is a step
+        ahead and does not notice) before it returns out[k]; sync="none": no cross-rank signal - for a caller that
+        only wants the traffic (the bench's timed region: nothing consumes the rows there).
+      The rows returned by push(t+1) are rewritten by the peers' copies of step t+2, which start when THEIR step t+2
+      has ended: consume them (or copy them out) before the next push.
+    Equal shards only. Needs one process per rank with peer access between the devices (one node)."""
+
+    def __init__(self, rows_local, cols, world_size, rank, dtype, device, group=None, signal_group=None, sync="barrier"):
+        from torch.multiprocessing.reductions import reduce_tensor
+        self.world, self.rank, self.n = int(world_size), int(rank), int(rows_local)
+        self.sync, self.signal_group = sync, (signal_group if signal_group is not None else group)
+        dev = torch.device(device)
+        self.out = [torch.zeros(self.n * self.world, cols, dtype=dtype, device=dev) for _ in range(2)]
+        mine = [reduce_tensor(o) for o in self.out]          # (rebuild function, IPC handle + geometry): picklable
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, mine, group=self.signal_group)
+        self.peer_out = {}
+        for p in range(self.world):
+            if p != self.rank:
+                self.peer_out[p] = [fn(*a) for fn, a in everyone[p]]
+        self.side = torch.cuda.Stream(device=dev)
+        self.ev_step = [torch.cuda.Event(), torch.cuda.Event()]
+        self.ev_copy = [torch.cuda.Event(), torch.cuda.Event()]
+        self.pushed = [False, False]
+        self.k = 0
+        dist.barrier(group=self.signal_group)       # nobody writes a peer's buffer before every rank has mapped them all
+
+    HOST_JOIN_TIMEOUT_S = PipelinedGather.HOST_JOIN_TIMEOUT_S
+
+    def _host_wait(self, ev):
+        t0 = None
+        while not ev.query():
+            now = time.monotonic()
+            if t0 is None:
+                t0 = now
+            elif now - t0 > self.HOST_JOIN_TIMEOUT_S:
+                raise TimeoutError("CopyGather: the peer copies did not complete within %.0f s" % self.HOST_JOIN_TIMEOUT_S)
+            time.sleep(0)
+
+    def push(self, local):
+        k, prev = self.k, 1 - self.k
+        lo, hi = self.rank * self.n, (self.rank + 1) * self.n
+        cur = torch.cuda.current_stream(local.device)
+        self.ev_step[k].record(cur)                  # the step that filled `local` ends here
+        self.side.wait_event(self.ev_step[k])        # (a wait on the SIDE stream: the step launches' stream gets none)
+        with torch.cuda.stream(self.side):
+            self.out[k][lo:hi].copy_(local, non_blocking=True)
+            for d in range(1, self.world):           # every rank starts with a different peer: no two writers on one link at once
+                p = (self.rank + d) % self.world
+                self.peer_out[p][k][lo:hi].copy_(local, non_blocking=True)
+            self.ev_copy[k].record(self.side)
+        self.pushed[k] = True
+        self.k = prev
+        if not self.pushed[prev]:
+            return None
+        self._host_wait(self.ev_copy[prev])          # before the producer's next step rewrites block `prev`
+        if self.sync == "barrier":
+            dist.barrier(group=self.signal_group)    # every rank's copies of that step are complete: out[prev] is whole
+        return self.out[prev]
+
+    def flush(self):
+        """Wait for the copies in flight on every rank; returns the most recent gathered rows."""
+        torch.cuda.current_stream().synchronize()
+        self.side.synchronize()
+        dist.barrier(group=self.signal_group)
+        return self.out[1 - self.k] if self.pushed[1 - self.k] else None

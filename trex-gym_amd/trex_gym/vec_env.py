@@ -84,6 +84,7 @@ class TrexVecEnv(spaces.Env):       # gym.Env where gym is importable; the surfa
         self._actions = None
         self._gather_buf = None
         self._pipe = None
+        self._copy_pipe = None
 
     # ---- tensor-native API (stays on device, stream-ordered, no host sync)
     def reset_tensor(self, mask=None):
@@ -167,6 +168,18 @@ class TrexVecEnv(spaces.Env):       # gym.Env where gym is importable; the surfa
             self._pipe = sharding.PipelinedGather(self.num_envs, rows.shape[1], self.world_size, rows.dtype,
                                                   self.device, self.process_group)
         return self._pipe.push(rows, copy=not (rows is self.rows and len(self._row_blocks) > 1), wait=wait, join=join)
+
+    def all_gather_rows_copy(self, signal_group=None, sync="barrier"):
+        """The pipelined exchange by peer copies instead of a collective kernel (sharding.CopyGather; needs
+        row_buffers=2): returns the rows gathered from the PREVIOUS step (None on the first call)."""
+        if self.world_size == 1:
+            return self.rows
+        if len(self._row_blocks) < 2 or self.global_num_envs != self.num_envs * self.world_size:
+            raise ValueError("the copy exchange reads the row block in place: row_buffers=2 and equal shards")
+        if self._copy_pipe is None:
+            self._copy_pipe = sharding.CopyGather(self.num_envs, self.rows.shape[1], self.world_size, self.rank, self.rows.dtype,
+                                                  self.device, self.process_group, signal_group, sync)
+        return self._copy_pipe.push(self.rows)
 
     def all_gather_obs(self):
         """[global N, 3J]: the observation columns of all_gather_rows()."""
