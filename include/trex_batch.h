@@ -115,9 +115,7 @@ int trex_batch_forget_buffers(TrexBatch *batch);
  * its slowest wave is, so the step kernel can rank the envs by the contact count of their previous step and deal
  * them to the SIMDs heaviest-with-lightest (device-side state only; results are bitwise independent of it).
  * mode -1 (default): on for batches of 2048 envs or more - below that most SIMDs hold at most two waves and there is
- * nothing to level -, 0: off (workgroup k runs env k), 1: on for any size. A batch of MORE than 4096 envs (the chip's wave
- * slots) is then stepped by a persistent launch - 4096 workgroups that draw env after env off the rank lists, heaviest
- * first - instead of one workgroup per env; mode 2 = on, but one workgroup per env at any size (for comparisons). */
+ * nothing to level -, 0: off (workgroup k runs env k), 1: on for any size. */
 int trex_batch_set_wave_balance(TrexBatch *batch, int mode);
 
 /* reward weights (trex_env.py:42-44): distance, energy, drift. Defaults 1.0, 0.005, 0.002. */

@@ -802,3 +802,31 @@ def test_single_env_facade_keeps_the_reference_surface(oracle64):
     assert env.seed(7) == [7]
     with pytest.raises(ValueError):
         env.step(np.zeros(3))
+
+
+def test_episode_statistics_in_the_infos_of_the_numpy_api():
+    """What bench.Monitor adds in the reference (trex_train.py:41-42): info['episode'] = {'r', 'l', 't'} on the step that
+    ends an env's episode - here the harness's time limit inside the step launch. r is the sum of the rewards the caller
+    was handed since the env's last reset (f64, like Monitor's Python floats), l the number of steps."""
+    n, limit = 5, 4
+    v = make_vec(n, max_episode_steps=limit)
+    v.reset()
+    v.set_episode_steps(torch.tensor([0, 1, 2, 3, 0], dtype=torch.int32))     # staggered ages: ends at steps 4, 3, 2, 1, 4
+    rng = np.random.default_rng(3)
+    lo, hi = v.action_space.low, v.action_space.high
+    ret, length = np.zeros(n), np.zeros(n, int)
+    seen = []
+    for t in range(9):
+        obs, rew, done, infos = v.step(rng.uniform(lo, hi, size=(n, 25)).astype(np.float32))
+        ret += rew; length += 1
+        for i in range(n):
+            if done[i]:
+                ep = infos[i]["episode"]
+                assert ep["l"] == length[i] and abs(ep["r"] - ret[i]) < 1e-5 * max(1.0, abs(ret[i])) and ep["t"] >= 0.0
+                seen.append((t, i, ep["l"]))
+                ret[i], length[i] = 0.0, 0
+            else:
+                assert infos[i] == {}
+    # first episodes are cut short by the staggered ages, the following ones last `limit` steps
+    assert [(t, i) for t, i, _ in seen if t < 4] == [(0, 3), (1, 2), (2, 1), (3, 0), (3, 4)]
+    assert all(l == limit for t, i, l in seen if t >= 4) and len(seen) == 5 + 5

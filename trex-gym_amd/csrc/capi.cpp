@@ -42,8 +42,8 @@ struct TrexBatch {
   TrexDeviceModel *dmodel = nullptr;
   TrexBatchArrays arr{};
   float wd = 1.0f, we = 0.005f, wk = 0.002f;  // trex_env.py:42-44
-  int balance_mode = -1;                       // trex_batch_set_wave_balance: -1 auto, 0 off, 1 on, 2 on without the persistent launch
-  int balance() const { return balance_mode < 0 ? (n >= 2048 ? 1 : 0) : balance_mode; }
+  int balance_mode = -1;                       // trex_batch_set_wave_balance: -1 auto, 0 off, 1 on
+  bool balance() const { return balance_mode < 0 ? n >= 2048 : balance_mode != 0; }
   std::vector<void *> allocs;
   // caller allocations already validated as memory of this device (base address, bytes known to be good):
   // the hot path pays one hash-free scan of a handful of entries, hipPointerGetAttributes only on a new one
@@ -479,7 +479,7 @@ int trex_batch_set_reward_weights(TrexBatch *b, float distance, float energy, fl
 
 int trex_batch_set_wave_balance(TrexBatch *b, int mode) {
   if (check_batch(b)) return TREX_E_INVALID;
-  if (mode < -1 || mode > 2) return fail(TREX_E_INVALID, "trex_batch_set_wave_balance: mode must be -1 (auto), 0 (off), 1 (on) or 2 (on, one workgroup per env)");
+  if (mode < -1 || mode > 1) return fail(TREX_E_INVALID, "trex_batch_set_wave_balance: mode must be -1 (auto), 0 (off) or 1 (on)");
   b->balance_mode = mode;
   return TREX_OK;
 }

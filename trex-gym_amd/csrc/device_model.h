@@ -58,9 +58,6 @@ struct TrexDeviceModel {
 #define TREX_MOTORS_BIT 256
 #define TREX_BAL_PHASE 0
 #define TREX_BAL_FINISHED 1
-#define TREX_BAL_CURSOR 2      /* persistent launch (more envs than wave slots): next rank to draw */
-#define TREX_BAL_EXITED 3      /* persistent launch: workgroups that have left it */
-#define TREX_WAVE_SLOTS 4096   /* 256 CUs x 4 SIMDs x 4 waves of 128 registers */
 #define TREX_BAL_COUNTS 16
 #define TREX_BAL_BINS 16
 #define TREX_BAL_LISTS 48
@@ -72,7 +69,6 @@ struct TrexBatchArrays {
   int32_t pad0_;
   int32_t *balance;       /* wave balance, device-side state only: [TREX_BAL_PHASE] which of the two list sets the next
                              step launch reads, [TREX_BAL_FINISHED] waves of the running launch that have ended,
-                             [TREX_BAL_CURSOR], [TREX_BAL_EXITED] the persistent launch's rank cursor and exit count,
                              [TREX_BAL_COUNTS + 16 p + c] envs filed under contact count c in set p,
                              [TREX_BAL_LISTS + (16 p + c) N + i] the i-th of them */
   int32_t max_episode_steps;  /* 0 = no limit; > 0: an env whose count reaches it is reset INSIDE the step launch */

@@ -373,11 +373,12 @@ struct KernelArgs {
 // MULTI: the launch advances every env by args.n_steps env-steps (open-loop action sequences): the state stays in
 // SGPRs / LDS between the steps and - what it is for - no wave ever waits for the slowest wave of a step: with one step
 // per launch the SIMDs idle a fifth of the launch behind its heaviest envs.
-// PERSIST (batches of more than 4096 envs, trex_step_persist_kernel): the launch has as many workgroups as the chip has wave
-// slots and every workgroup takes env after env off the rank lists, heaviest class first (k = the rank it drew), instead
-// of one workgroup per env in workgroup order.
-template <bool RESET, bool DEBUG, bool MULTI, bool PERSIST = false>
-__device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int wg) {   // wg: blockIdx.x, or the rank drawn
+// (Measured in round 4 and NOT kept - DESIGN.md 6: a PERSISTENT launch for batches beyond the 4096 wave slots, 4096 workgroups
+// that draw env after env off the rank lists through an atomic cursor, heaviest first. Bitwise the same rows; 10.7 M env-steps/s
+// at 8192 envs and 13.0 M at 32768 against 11.4 M / 13.3 M for one workgroup per env: the dispatcher refills the slots at
+// least as well, and the env loop around this body made the compiler hoist constants out of it - 7 spilled registers.)
+template <bool RESET, bool DEBUG, bool MULTI>
+__device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int wg) {   // wg: blockIdx.x
   __shared__ WaveLds W;
   const int tid = threadIdx.x;
   const TrexDeviceModel *__restrict__ M = args.model;
@@ -395,7 +396,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
     bal_phase = uni(B[TREX_BAL_PHASE]);
     const int32_t *cnt = B + TREX_BAL_COUNTS + TREX_BAL_BINS * bal_phase;
     const int k = wg, q = k >> 10, m = min(1024, args.n_envs - (q << 10));
-    int r = (PERSIST || q == 0) ? k : (q << 10) + (m - 1 - (k & 1023));   // (PERSIST: ranks are drawn in order, heaviest first)
+    int r = q == 0 ? k : (q << 10) + (m - 1 - (k & 1023));
     // (not better, measured: SIMD j taking rank j and the 3 LIGHTEST envs still to be dealt - 11.07 M against 11.13 M
     // at 4096 envs, 13.02 M against 13.18 M at 32768: which light mates a heavy wave has does not matter)
     const int lane_ = (int)threadIdx.x;
@@ -518,7 +519,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
 #define TREX_PRIO_T2 3
 #define TREX_PRIO_T3 6
 #endif
-  const bool aged_launch = !PERSIST && args.n_envs <= 4096;
+  const bool aged_launch = args.n_envs <= 4096;
   const int wave_pair = (wg >> 11) & 1;      // 0: the two older waves of the SIMD, 1: the two younger
   auto set_sweep_priority = [&](int contacts) {
     int v = contacts >= TREX_PRIO_T3 ? 3 : (contacts >= TREX_PRIO_T2 ? 2 : (contacts >= TREX_PRIO_T1 ? 1 : 0));
@@ -1661,11 +1662,11 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
           {
             int jt_;
             static_assert(NJMAX == 25, "the jump table below has 25 entries");
-            asm volatile("s_getpc_b64 s[100:101]\n\t"
+            asm volatile("s_getpc_b64 vcc\n\t"
                          "s_lshl3_add_u32 %[t], %[j], 8\n\t"
-                         "s_add_u32 s100, s100, %[t]\n\t"
-                         "s_addc_u32 s101, s101, 0\n\t"
-                         "s_setpc_b64 s[100:101]\n\t"
+                         "s_add_u32 vcc_lo, vcc_lo, %[t]\n\t"
+                         "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"
+                         "s_setpc_b64 vcc\n\t"
                          "v_fmac_f32_e32 %[y], %[sd], %[b1]\n\t"
                          "s_branch 9f\n\t"
                          "v_fmac_f32_e32 %[y], %[sd], %[b2]\n\t"
@@ -1718,7 +1719,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
                          "9:\n\t"
                          : [y] "+v"(y), [t] "=&s"(jt_)
                          : [sd] "s"(sd), [j] "s"(j), [b1] "v"(Bm[0]), [b2] "v"(Bm[1]), [b3] "v"(Bm[2]), [b4] "v"(Bm[3]), [b5] "v"(Bm[4]), [b6] "v"(Bm[5]), [b7] "v"(Bm[6]), [b8] "v"(Bm[7]), [b9] "v"(Bm[8]), [b10] "v"(Bm[9]), [b11] "v"(Bm[10]), [b12] "v"(Bm[11]), [b13] "v"(Bm[12]), [b14] "v"(Bm[13]), [b15] "v"(Bm[14]), [b16] "v"(Bm[15]), [b17] "v"(Bm[16]), [b18] "v"(Bm[17]), [b19] "v"(Bm[18]), [b20] "v"(Bm[19]), [b21] "v"(Bm[20]), [b22] "v"(Bm[21]), [b23] "v"(Bm[22]), [b24] "v"(Bm[23]), [b25] "v"(Bm[24])
-                         : "s100", "s101", "scc");
+                         : "vcc", "scc");
           }
         }
         // motor rows (joints beyond nb are null rows: y = 0, bounds 0), hand-placed: 5 issue slots per row (the compiler's
@@ -2089,8 +2090,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
       if (at < args.n_envs) B[TREX_BAL_LISTS + (size_t)(w * TREX_BAL_BINS + bin) * args.n_envs + at] = env;
       // (no fence: the lists are read by the NEXT launch only; within this launch the last wave needs nothing but
       // the count of ended waves, an atomic)
-      // (PERSIST: the last WORKGROUP to leave the launch does this, trex_step_persist_kernel)
-      if (!PERSIST && atomicAdd(&B[TREX_BAL_FINISHED], 1) == args.n_envs - 1) {
+      if (atomicAdd(&B[TREX_BAL_FINISHED], 1) == args.n_envs - 1) {
         B[TREX_BAL_FINISHED] = 0;
         for (int i = 0; i < TREX_BAL_BINS; i++) B[TREX_BAL_COUNTS + TREX_BAL_BINS * bal_phase + i] = 0;
         B[TREX_BAL_PHASE] = w;
@@ -2103,39 +2103,6 @@ template <bool RESET, bool DEBUG>
 __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) { trex_step_body<RESET, DEBUG, false>(args, (int)blockIdx.x); }
 // S env-steps per launch (trex_batch_step_many)
 __global__ __launch_bounds__(64, 4) void trex_step_many_kernel(KernelArgs args) { trex_step_body<false, false, true>(args, (int)blockIdx.x); }
-// More envs than the chip has wave slots (4096 = 256 CUs x 16): a launch of one workgroup per env is refilled by the
-// dispatcher in workgroup order as slots fall free, and ends with a tail of whatever envs came last - 8192 envs stepped at
-// 11.5 M env-steps/s where two free-running batches of 4096 reach 14.0 M (profiles/r03_group_pipeline.txt). Here the grid
-// IS the wave slots, and every workgroup draws rank after rank from one atomic cursor: the heaviest contact class first,
-// the lightest envs last (longest-processing-time-first: the tail is as short as the lightest env), no slot ever waits for
-// the dispatcher. Which workgroup steps which env changes nothing in the results (one env per wave, no shared state:
-// tests/test_gpu_parity.py::test_rank_lists_cover_every_env_at_ragged_sizes). Device-side state only: the cursor is
-// zeroed by the last workgroup to leave - every workgroup has drawn its final, failing rank by then -, which also clears
-// the counts the launch read and flips the list phase; a captured graph replays correctly.
-__global__ __launch_bounds__(64, 4) void trex_step_persist_kernel(KernelArgs args) {
-  int32_t *B = args.arr.balance;
-  // first env of every workgroup: dealt like a resident launch of TREX_WAVE_SLOTS envs (workgroup b sits on SIMD b mod
-  // 1024: ranks 0..1023 in order, every later block of 1024 in reverse - the sums of work per SIMD are level; drawn in
-  // workgroup order instead, SIMD 0 gets the heaviest env of every block: 10.1 M against 11.4 M env-steps/s at 8192 envs)
-  const int b = (int)blockIdx.x, q = b >> 10;
-  int k = q == 0 ? b : (q << 10) + (1023 - (b & 1023));     // (the launcher guarantees n_envs > TREX_WAVE_SLOTS = gridDim.x)
-  for (;;) {   // ... then rank after rank off the cursor, heaviest first
-    trex_step_body<false, false, false, true>(args, k);
-    k = 0;
-    if (threadIdx.x == 0) k = TREX_WAVE_SLOTS + atomicAdd(&B[TREX_BAL_CURSOR], 1);
-    k = uni(k);
-    if (k >= args.n_envs) break;
-  }
-  if (threadIdx.x == 0 && atomicAdd(&B[TREX_BAL_EXITED], 1) == (int)gridDim.x - 1) {
-    B[TREX_BAL_EXITED] = 0;
-    B[TREX_BAL_CURSOR] = 0;
-    if (args.bal) {
-      const int p = B[TREX_BAL_PHASE];
-      for (int i = 0; i < TREX_BAL_BINS; i++) B[TREX_BAL_COUNTS + TREX_BAL_BINS * p + i] = 0;
-      B[TREX_BAL_PHASE] = p ^ 1;
-    }
-  }
-}
 
 // ---------------------------------------------------------------- small utility kernels
 __global__ void trex_pack_state_kernel(const TrexDeviceModel *M, TrexBatchArrays arr, int n, float *out, int pack) {
@@ -2309,14 +2276,10 @@ hipError_t trex_launch_step(const TrexDeviceModel *model, TrexBatchArrays arr, i
                             int balance, int pen_in_rows) {
   // balance: the env-to-wave assignment by contact rank (trex_batch_set_wave_balance decides; capi.cpp). Diagnostics
   // launches keep env k in workgroup k (the stamped build is balanced like the product: it reports the env of every wave)
-  // balance: 0 off, 1 lists (+ the persistent launch beyond 4096 envs), 2 lists with one workgroup per env at any size
   int32_t *perm = ((debug && !TREX_STAMPS) || !balance) ? nullptr : arr.balance;
   KernelArgs a{model, arr, n, actions, obs, reward, done, done_f, obs_stride, scal_stride, penalties, nullptr, perm, wd, we, wk, debug,
                1, 0, pen_in_rows};
-  if (balance == 1 && !debug && !TREX_STAMPS && n > TREX_WAVE_SLOTS) {
-    hipLaunchKernelGGL(trex_step_persist_kernel, dim3(TREX_WAVE_SLOTS), dim3(64), 0, stream, a);
-    return hipGetLastError();
-  }
+
 #if TREX_STAMPS   // diagnostic build: the PRODUCT instantiation, stamped (the dump of <false, true> would change its code)
   hipLaunchKernelGGL((trex_step_kernel<false, false>), dim3(n), dim3(64), 0, stream, a);
 #else

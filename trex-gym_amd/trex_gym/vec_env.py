@@ -16,6 +16,8 @@ into it; `done` holds the flags as bool, `penalties` [n, 3] the three reward ter
 Multi-GPU: one process per GPU, env ids sharded by contiguous range (trex_gym.sharding); the only
 exchange is the all-gather of that row block (all_gather_rows / all_gather_rows_pipelined).
 """
+import time
+
 import numpy as np
 import torch
 
@@ -85,6 +87,7 @@ class TrexVecEnv(spaces.Env):       # gym.Env where gym is importable; the surfa
         self._gather_buf = None
         self._pipe = None
         self._copy_pipe = None
+        self._ep_ret = self._ep_len = None      # episode statistics of the numpy API (step_wait)
 
     # ---- tensor-native API (stays on device, stream-ordered, no host sync)
     def reset_tensor(self, mask=None):
@@ -187,15 +190,33 @@ class TrexVecEnv(spaces.Env):       # gym.Env where gym is importable; the surfa
 
     # ---- baselines VecEnv API (host numpy in/out)
     def reset(self):
+        if self._ep_ret is not None:
+            self._ep_ret[:] = 0.0
+            self._ep_len[:] = 0
         return self.reset_tensor().cpu().numpy()
 
     def step_async(self, actions):
         self._actions = torch.as_tensor(np.asarray(actions, np.float32)).to(self.device, non_blocking=True)
 
     def step_wait(self):
+        """-> obs, rewards, dones, infos as numpy / dicts. The reference wraps its env in baselines' bench.Monitor
+        (trex_train.py:41-42), whose info['episode'] = {'r': episode return, 'l': length, 't': seconds since the monitor was
+        made} is what ppo2.learn averages into eprewmean / eplenmean: the env whose episode ENDS with this step (the harness's
+        time limit inside the launch, or a contained env) carries that entry here too."""
         obs, rew, done = self.step_tensor(self._actions)
+        obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        if self._ep_ret is None:
+            self._ep_ret, self._ep_len = np.zeros(self.num_envs, np.float64), np.zeros(self.num_envs, np.int64)
+            self._t_start = time.time()
+        self._ep_ret += rew          # (Monitor sums Python floats: f64)
+        self._ep_len += 1
         infos = [{} for _ in range(self.num_envs)]
-        return obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy(), infos
+        for i in np.flatnonzero(done):
+            infos[i]["episode"] = {"r": round(float(self._ep_ret[i]), 6), "l": int(self._ep_len[i]),
+                                   "t": round(time.time() - self._t_start, 6)}
+            self._ep_ret[i] = 0.0
+            self._ep_len[i] = 0
+        return obs, rew, done, infos
 
     def step(self, actions):
         self.step_async(actions)
