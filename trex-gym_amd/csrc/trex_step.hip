@@ -326,20 +326,15 @@ constexpr int BREC = 5;                  // float4s per record
 struct WaveLds {
   float4 body[32 * BREC];     // 2560 B; after the row walks: z0 stash [6][64] for the base twist change
   union {
-    struct {
-      float aba[32][28];      // tip-to-base pass: articulated inertia (21) + bias force (6) per body      3584 B
-      float rtab[32][9];      // PAIR launches: body rotations, handed to the wave that runs the tree phases 1152 B
-    } t;
+    float aba[32][28];        // tip-to-base pass: articulated inertia (21) + bias force (6) per body      3584 B
     float4 desc[64][4];       // B build: column descriptor of the row on lane L: chain | zc[6] | z0[6]     4096 B
     float4 cg[336];           // contact generation: CgLds (below)                                          5376 B
   } u;
   float cpt[MAXC][8];         // contact points: body, x, y, z (rel. base origin), distance     416 B
   float st[6][TL];            // per body lane, parked across the phases: q, qd, motor torque, target, updated rate, 1/M^-1_jj  768 B
-  float xch[40];              // PAIR launches, between the two waves of a workgroup: [0..5] base twist w, v | [6] env | [7] substeps
-                              // of this step | [8..28] Cholesky factor of the base's articulated inertia | [29..34] base acceleration
 };
 enum { ST_Q, ST_QD, ST_TAU, ST_TARGET, ST_NQD, ST_MDG };
-static_assert(sizeof(WaveLds) <= 10240, "16 envs per CU need <= 10 KB of LDS each");
+static_assert(sizeof(WaveLds) <= 10240, "16 workgroups per CU need <= 10 KB of LDS each");
 // Contact generation works in the union area (the inertia slots are written after it):
 constexpr int CG_WORDS = 32;             // in-margin mask words per body: bit j of word w <-> vertex 32 j + w of the body (up to 1024)
 struct CgLds {
@@ -382,27 +377,16 @@ struct KernelArgs {
 // that draw env after env off the rank lists through an atomic cursor, heaviest first. Bitwise the same rows; 10.7 M env-steps/s
 // at 8192 envs and 13.0 M at 32768 against 11.4 M / 13.3 M for one workgroup per env: the dispatcher refills the slots at
 // least as well, and the env loop around this body made the compiler hoist constants out of it - 7 spilled registers.)
-// PAIR (trex_step_pair_kernel): a workgroup of TWO waves = two envs. Each wave runs its env as in the single-env launch -
-// kinematics, contact generation, row walks, B build, sweeps, integration - except for the four phases that work with one
-// lane per BODY (velocities / inertias / bias forces, ABA pass 2, the base's Cholesky factor, ABA pass 3: a fifth of a
-// wave's cycles with 26 of 64 lanes busy, pass 2 with at most 7): those run ONCE, on the first wave, for both envs - lanes
-// 0..31 the bodies of wave 0's env, lanes 32..63 those of wave 1's, every LDS address and shuffle source offset by the
-// half - while the second wave waits at a barrier and leaves its issue slots to the other waves of its SIMD. The same
-// arithmetic per lane: bitwise the rows of the single-env launch (scripts/state_digest.py).
-#define WSYNC() do { if (PAIR) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); else __syncthreads(); } while (0)
-template <bool RESET, bool DEBUG, bool MULTI, bool PAIR = false>
-__device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int wg_in) {   // wg_in: blockIdx.x
-  static_assert(!PAIR || (!RESET && !DEBUG && !MULTI), "the pair form exists for the product step launch only");
-  __shared__ WaveLds Wpair[PAIR ? 2 : 1];
-  const int wave = PAIR ? uni((int)threadIdx.x >> 6) : 0;
-  // (PAIR: the LDS of this wave's env is addressed through ONE base register the compiler takes for lane-dependent - a
-  // wave-uniform base made it precompute an address per access as scalars: 226 spilled scalar registers, 80 reloads in the
-  // B build alone)
-  int wave_v = PAIR ? (int)threadIdx.x >> 6 : 0;
-  if (PAIR) asm volatile("" : "+v"(wave_v));
-  WaveLds &W = Wpair[wave_v];
-  const int wg = PAIR ? 2 * wg_in + wave : wg_in;       // the index the env-to-wave deal and the priorities go by
-  const int tid = (int)threadIdx.x & 63;
+// (Measured in round 4 and NOT kept - DESIGN.md 6, git history "EXPERIMENT ... two envs per workgroup": the four lane-per-body tree
+// phases - velocities / inertias / bias forces, ABA pass 2, the base's Cholesky factor, ABA pass 3: a fifth of a wave's cycles at
+// 26 of 64 lanes - run ONCE for the two envs of a two-wave workgroup, lanes 0..31 / 32..63, the partner wave waiting at a
+// barrier. Same rows up to rounding; 11.40 M against 11.53 M env-steps/s at 4096 envs and the heaviest env alone 0.298 against
+// 0.288 ms: two workgroup barriers per substep, the lockstep of two envs of different length and the hand-over of rotations,
+// twists and the base factor through LDS cost more than halving the instruction stream of those phases gives back.)
+template <bool RESET, bool DEBUG, bool MULTI>
+__device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int wg) {   // wg: blockIdx.x
+  __shared__ WaveLds W;
+  const int tid = threadIdx.x;
   const TrexDeviceModel *__restrict__ M = args.model;
   // Which env this wave runs. All waves of the headline launch are resident at once and a SIMD is done when its
   // slowest wave is, so the envs are dealt by the contact count of their PREVIOUS step launch: every wave filed its
@@ -421,7 +405,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
     int r = q == 0 ? k : (q << 10) + (m - 1 - (k & 1023));
     // (not better, measured: SIMD j taking rank j and the 3 LIGHTEST envs still to be dealt - 11.07 M against 11.13 M
     // at 4096 envs, 13.02 M against 13.18 M at 32768: which light mates a heavy wave has does not matter)
-    const int lane_ = tid;
+    const int lane_ = (int)threadIdx.x;
     const int mine = lane_ < TREX_BAL_BINS ? cnt[lane_] : 0;   // the 16 counts in one load, lane c holds count c
     int b = TREX_BAL_BINS - 1, total = 0;
 #pragma unroll
@@ -518,7 +502,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
       W.st[ST_NQD][tid] = 0.f;
     }
   }
-  WSYNC();
+  __syncthreads();
   const int n_sub = RESET ? (do_reset ? 1 : 0) : M->n_substeps;
   // Wave priority: the launch lasts as long as its slowest wave, and with one env per wave that is an env with
   // many contact rows. During its sweeps such a wave wins the issue arbitration against the lighter waves of
@@ -673,7 +657,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
       W.st[ST_Q][l] = l < nb ? Mo()->q_start[l] : 0.f;
       W.st[ST_QD][l] = 0.f; W.st[ST_TAU][l] = 0.f;
     }
-    WSYNC();
+    __syncthreads();
   };
   const int n_launch_steps = MULTI ? args.n_steps : 1;
 #pragma unroll 1
@@ -699,37 +683,28 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
     time_up = age >= args.arr.max_episode_steps;
   }
   const int n_total = n_sub + ((!RESET && time_up) ? 1 : 0);
-  int n_loop = n_total;
-  if (PAIR) {   // the two envs of the workgroup run the same number of loop trips (an env whose episode ends takes one more substep)
-    if (lane_id() == 0) W.xch[7] = __int_as_float(n_total);
-    __syncthreads();
-    n_loop = max(uni(__float_as_int(Wpair[0].xch[7])), uni(__float_as_int(Wpair[PAIR ? 1 : 0].xch[7])));
-  }
 #pragma unroll 1
-  for (int sub = 0; sub < n_loop; sub++) {
-    // lane id and what derives from it are RE-derived at the start of every phase (RELANE): a value that
-    // lived from the top of the substep would be spilled across the phases in between
-    int lt, bl;                        // bl: index into the [32]-wide model / state rows (lanes >= 32 alias, never used)
-    bool is_body, is_joint;
-#define RELANE() do { lt = lane_id(); bl = lt & (TL - 1); is_body = lt < nb; is_joint = lt >= 1 && lt < nb; } while (0)
-    int psrc, depth;
-    float R[9], r[3];
-    float Sa[3], dpar[3];   // joint axis (world) and offset from the parent's origin: re-read from the record per phase
-    int nc = 0;
-    const bool act = !PAIR || sub < n_total;   // (PAIR: a wave whose env is done with this step only keeps the barriers)
-    if (act) {
+  for (int sub = 0; sub < n_total; sub++) {
     if (!RESET && sub == n_sub) {   // time is up: the step is complete, the new episode starts (settle substep follows)
       finish_step();
       to_start_pose();
       motors_on = false;            // remove_joint_control, trex_robot.py:309
     }
+    // lane id and what derives from it are RE-derived at the start of every phase (RELANE): a value that
+    // lived from the top of the substep would be spilled across the phases in between
+    int lt, bl;                        // bl: index into the [32]-wide model / state rows (lanes >= 32 alias, never used)
+    bool is_body, is_joint;
+#define RELANE() do { lt = lane_id(); bl = lt & (TL - 1); is_body = lt < nb; is_joint = lt >= 1 && lt < nb; } while (0)
     RELANE();
+    int psrc, depth;
     {
       const TrexDeviceModel *Mi = Mo();
       const int parent = is_body ? Mi->parent[bl] : 0;
       psrc = parent < 0 ? 0 : parent;
       depth = is_body ? Mi->depth[bl] : -1;
     }
+    float R[9], r[3];
+    float Sa[3], dpar[3];   // joint axis (world) and offset from the parent's origin: re-read from the record per phase
     {
       float dpar0[3], Sa0[3];
       forward_kinematics(lt, psrc, depth, R, r, dpar0, Sa0);
@@ -770,7 +745,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
     //     the lowest vertex index, as in the oracle.
     // Pass B revisits a body's in-margin vertices only when more than one point per body is kept (K >= 2).
     // The points go to LDS (W.cpt) in contact order; only their number nc stays in a register.
-    nc = 0;
+    int nc = 0;
     {
       const TrexDeviceModel *Mi = Mo();
       const int hull_v0 = Mi->hull_start[is_body ? lt : nb], hull_v1 = Mi->hull_start[is_body ? lt + 1 : nb];
@@ -822,7 +797,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
           G.ent[e][1] = make_float4(Rz[0], Rz[1], Rz[2], zbc);
         }
       }
-      WSYNC();
+      __syncthreads();
       SUBSTAMP(9);    // broad phase + table
       // ---- the scan
       if (total > 0) {
@@ -856,7 +831,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
           }
         }
       }
-      WSYNC();
+      __syncthreads();
       SUBSTAMP(10);   // scan
       // ---- per body: its deepest vertex
       unsigned active_mask = 0u;
@@ -1076,15 +1051,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
     RELANE();
     RETREE();
     REAXIS();
-    }   // act (kinematics, contact generation)
 
-    Chol6 I0c;
-    float a0[6];
-    float nw[3], nv[3];
-#ifndef TREX_GENERIC_TREE
-#define TREX_GENERIC_TREE 0      // diagnostic: the single-env launch through the two-env form of the tree phases (with one half)
-#endif
-    if (!PAIR && !TREX_GENERIC_TREE) {
     // ================================================================ tree dynamics
     // ---- rigid-body spatial inertia about the body origin, bias force (both straight to the body's LDS slot:
     // the tip-to-base pass works on LDS-resident inertias), velocity-product acceleration cv (registers)
@@ -1189,20 +1156,20 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
         }
       }
       if (is_body) {
-        float *o = W.u.t.aba[bl];
+        float *o = W.u.aba[bl];
 #pragma unroll
         for (int k = 0; k < 6; k++) { o[k] = IA.A[k]; o[15 + k] = IA.C[k]; o[21 + k] = pA[k]; }
 #pragma unroll
         for (int k = 0; k < 9; k++) o[6 + k] = IA.B[k];
       }
     }
-    WSYNC();
+    __syncthreads();
     STAMP(2);
     RELANE();
     RETREE();
     REAXIS();
 
-    // ---- ABA pass 2 (tip to base) on LDS-resident inertias: slot b of W.u.t.aba holds body b's rigid-body inertia
+    // ---- ABA pass 2 (tip to base) on LDS-resident inertias: slot b of W.u.aba holds body b's rigid-body inertia
     // (21) and bias force (6) about its own origin. Level by level, the lanes AT depth d take their slot, add
     // what their children left in theirs (already shifted to this body's origin; fixed order), form U, 1/D, u
     // (which go to the body record: pass 3 and the row walks read them there), remove the joint's freedom,
@@ -1213,13 +1180,13 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
       const float tau_j = -Mi->damp[bl] * W.st[ST_QD][bl];  // explicit joint damping torque
       for (int d = maxdepth; d >= 0; d--) {
         if (depth == d) {
-          float *o = W.u.t.aba[bl];
+          float *o = W.u.aba[bl];
           const unsigned ch4 = __float_as_uint(reinterpret_cast<const float *>(&W.body[BREC * bl + 4])[3]);
           float acc[27];
           {
             // own slot and first child's in flight together (most bodies have exactly one child)
             const int c0 = (int)(ch4 & 255u);
-            const float *c = W.u.t.aba[c0 == 255 ? bl : c0];
+            const float *c = W.u.aba[c0 == 255 ? bl : c0];
             const float w0 = c0 == 255 ? 0.f : 1.f;
 #pragma unroll
             for (int k = 0; k < 27; k++) acc[k] = __builtin_fmaf(w0, c[k], o[k]);
@@ -1228,7 +1195,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
           for (int kc = 1; kc < MAXCH; kc++) {   // further children, fixed order (packed without gaps)
             const int ch = (int)((ch4 >> (8 * kc)) & 255u);
             if (ch == 255) break;
-            const float *c = W.u.t.aba[ch];
+            const float *c = W.u.aba[ch];
 #pragma unroll
             for (int k = 0; k < 27; k++) acc[k] += c[k];
           }
@@ -1303,7 +1270,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
             for (int k = 0; k < 9; k++) o[6 + k] = IA.B[k];
           }
         }
-        WSYNC();
+        __syncthreads();
       }
       if (lt < TL && !is_joint) {   // base and unused lanes: inert records
         float4 *rec = &W.body[BREC * lt];
@@ -1318,8 +1285,10 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
     REAXIS();
 
     // ---- floating base: a0 = -(IA_0)^-1 pA_0; the Cholesky factor of IA_0 is wave-uniform (SGPRs)
+    Chol6 I0c;
+    float a0[6];
     {
-      const float *o = W.u.t.aba[0];   // every lane reads the same words: LDS broadcast
+      const float *o = W.u.aba[0];   // every lane reads the same words: LDS broadcast
       Sym6 I0;
 #pragma unroll
       for (int k = 0; k < 6; k++) { I0.A[k] = o[k]; I0.C[k] = o[15 + k]; }
@@ -1368,6 +1337,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
       }
     }
     // ---- unconstrained velocity update
+    float nw[3], nv[3];
     {
       const float vmax = M->prm[TP_MAX_COORD_VEL];
       float wxv[3];
@@ -1394,354 +1364,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
         }
       }
     }
-    } else {
-      // ---- PAIR: hand the rotations and the base twist of this wave's env to the first wave ...
-      if (act) {
-        const int l_ = lane_id();
-        if (l_ < TL) {
-          float *rt = W.u.t.rtab[l_];
-#pragma unroll
-          for (int c = 0; c < 9; c++) rt[c] = R[c];
-        }
-        if (l_ == 0) {
-#pragma unroll
-          for (int c = 0; c < 3; c++) { W.xch[c] = bw[c]; W.xch[3 + c] = bv[c]; }
-          W.xch[6] = __int_as_float(env);
-        }
-      }
-      if (PAIR) __syncthreads(); else WSYNC();      // both envs' body records, state rows, rotations and twists are in LDS
-      if (wave == 0) {
-        // ... which runs the lane-per-body phases for BOTH: H = the LDS of the lane's half, hoff = its first lane
-        WaveLds *H;
-        int hoff;
-#define RELANE2() do { lt = lane_id(); bl = lt & (TL - 1); hoff = PAIR ? (lt & TL) : 0; H = &Wpair[PAIR ? (lt >> 5) : 0];            \
-                       is_body = (PAIR ? bl : lt) < nb; is_joint = (PAIR ? bl : lt) >= 1 && (PAIR ? bl : lt) < nb; } while (0)
-#define REAXIS2() do { const float4 q0_ = H->body[BREC * bl], q4_ = H->body[BREC * bl + 4];                          \
-                       Sa[0] = is_joint ? q0_.x : 0.f; Sa[1] = is_joint ? q0_.y : 0.f; Sa[2] = is_joint ? q0_.z : 0.f; \
-                       dpar[0] = q4_.x; dpar[1] = q4_.y; dpar[2] = q4_.z; } while (0)
-#define RETREE2() do { const int lk_ = __float_as_int(reinterpret_cast<const float *>(&H->body[BREC * bl + 3])[2]); \
-                       psrc = lk_ & 255; depth = is_body ? (lk_ >> 8) : -1; } while (0)
-        RELANE2();
-        RETREE2();
-        REAXIS2();
-    // ================================================================ tree dynamics
-    // ---- rigid-body spatial inertia about the body origin, bias force (both straight to the body's LDS slot:
-    // the tip-to-base pass works on LDS-resident inertias), velocity-product acceleration cv (registers)
-    float cv[6];
-    {
-      Sym6 IA;
-      float pA[6];
-      const float qd = H->st[ST_QD][bl];
-      // spatial velocity of every body ABOUT ITS OWN ORIGIN for the base twist and the joint rates
-      float vel[6];
-#pragma unroll
-      for (int c = 0; c < 3; c++) { vel[c] = H->xch[c]; vel[3 + c] = H->xch[3 + c]; }
-      for (int d = 1; d <= maxdepth; d++) {
-        float pv[6];
-#pragma unroll
-        for (int c = 0; c < 6; c++) pv[c] = wshfl(vel[c], psrc + hoff);
-        if (depth == d) {
-          float wxd[3];
-          cross3(pv, dpar, wxd);   // velocity of the parent-body point at this body's origin
-#pragma unroll
-          for (int c = 0; c < 3; c++) { vel[c] = pv[c] + Sa[c] * qd; vel[3 + c] = pv[3 + c] + wxd[c]; }
-        }
-      }
-      float Rh[9];
-#pragma unroll
-      for (int c = 0; c < 9; c++) Rh[c] = H->u.t.rtab[bl][c];
-      const TrexDeviceModel *Mi = Mo();
-      float comb[3], inb[6];
-      const float mscale = args.arr.domain ? args.arr.mass_scale[(size_t)__float_as_int(H->xch[6]) * TL + bl] : 1.0f;
-      const float mass = Mi->mass[bl] * mscale;
-#pragma unroll
-      for (int c = 0; c < 3; c++) comb[c] = Mi->com[c][bl];
-#pragma unroll
-      for (int c = 0; c < 6; c++) inb[c] = Mi->inertia[c][bl];
-      const float grav = Mi->prm[TP_GRAVITY], kdamp = Mi->prm[TP_LINK_DAMPING];
-      float comw[3], Icw[6];   // comw = COM offset from the body origin, world axes
-      {
-        matvec3(Rh, comb, comw);
-        // Ic_world = R Ib R^T (symmetric)
-        float t[9];
-        const float Ib[9] = {inb[0], inb[1], inb[2], inb[1], inb[3], inb[4], inb[2], inb[4], inb[5]};
-        matmul3(Rh, Ib, t);
-        const int ia[6] = {0, 0, 0, 1, 1, 2}, ib[6] = {0, 1, 2, 1, 2, 2};
-#pragma unroll
-        for (int k = 0; k < 6; k++)
-          Icw[k] = mscale * (t[3 * ia[k]] * Rh[3 * ib[k]] + t[3 * ia[k] + 1] * Rh[3 * ib[k] + 1] + t[3 * ia[k] + 2] * Rh[3 * ib[k] + 2]);
-      }
-      {
-        const float cc = dot3(comw, comw);
-        IA.A[0] = Icw[0] + mass * (cc - comw[0] * comw[0]);
-        IA.A[1] = Icw[1] - mass * comw[0] * comw[1];
-        IA.A[2] = Icw[2] - mass * comw[0] * comw[2];
-        IA.A[3] = Icw[3] + mass * (cc - comw[1] * comw[1]);
-        IA.A[4] = Icw[4] - mass * comw[1] * comw[2];
-        IA.A[5] = Icw[5] + mass * (cc - comw[2] * comw[2]);
-        // B = m * [c]x
-        IA.B[0] = 0.f;              IA.B[1] = -mass * comw[2];  IA.B[2] = mass * comw[1];
-        IA.B[3] = mass * comw[2];   IA.B[4] = 0.f;              IA.B[5] = -mass * comw[0];
-        IA.B[6] = -mass * comw[1];  IA.B[7] = mass * comw[0];   IA.B[8] = 0.f;
-        IA.C[0] = mass; IA.C[1] = 0.f; IA.C[2] = 0.f; IA.C[3] = mass; IA.C[4] = 0.f; IA.C[5] = mass;
-      }
-      if (!is_body) {
-#pragma unroll
-        for (int k = 0; k < 6; k++) { IA.A[k] = (k == 0 || k == 3 || k == 5) ? 1.f : 0.f; IA.C[k] = IA.A[k]; }
-#pragma unroll
-        for (int k = 0; k < 9; k++) IA.B[k] = 0.f;
-      }
-      {
-        float h[6];
-        sym6_mul(IA, vel, h);
-        // v x* h
-        float a[3], b[3], c[3];
-        cross3(vel, h, a); cross3(vel + 3, h + 3, b); cross3(vel, h + 3, c);
-#pragma unroll
-        for (int k = 0; k < 3; k++) { pA[k] = a[k] + b[k]; pA[3 + k] = c[k]; }
-        float f[3] = {0.f, 0.f, -mass * grav}, n[3] = {0.f, 0.f, 0.f};
-        if (kdamp > 0.f) {
-          float vc[3], wxc[3], Iw[3];
-          cross3(vel, comw, wxc);
-#pragma unroll
-          for (int k = 0; k < 3; k++) vc[k] = vel[3 + k] + wxc[k];
-          const float sv = sqrtf(dot3(vc, vc)), sw = sqrtf(dot3(vel, vel));
-          sym3_mul(Icw, vel, Iw);
-#pragma unroll
-          for (int k = 0; k < 3; k++) {
-            f[k] -= mass * vc[k] * (kdamp + kdamp * sv);
-            n[k] -= Iw[k] * (kdamp + kdamp * sw);
-          }
-        }
-        float cxf[3];
-        cross3(comw, f, cxf);
-#pragma unroll
-        for (int k = 0; k < 3; k++) { pA[k] -= n[k] + cxf[k]; pA[3 + k] -= f[k]; }
-        // c = vel x (S qd), S = [Sa; 0]
-        float sq[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) sq[k] = Sa[k] * qd;
-        float x0[3], x2[3];
-        cross3(vel, sq, x0); cross3(vel + 3, sq, x2);
-#pragma unroll
-        for (int k = 0; k < 3; k++) { cv[k] = x0[k]; cv[3 + k] = x2[k]; }
-        if (!is_body) {
-#pragma unroll
-          for (int k = 0; k < 6; k++) { pA[k] = 0.f; cv[k] = 0.f; }
-        }
-      }
-      if (is_body) {
-        float *o = H->u.t.aba[bl];
-#pragma unroll
-        for (int k = 0; k < 6; k++) { o[k] = IA.A[k]; o[15 + k] = IA.C[k]; o[21 + k] = pA[k]; }
-#pragma unroll
-        for (int k = 0; k < 9; k++) o[6 + k] = IA.B[k];
-      }
-    }
-    WSYNC();
-    RELANE2();
-    RETREE2();
-    REAXIS2();
-
-    // ---- ABA pass 2 (tip to base) on LDS-resident inertias: slot b of H->u.t.aba holds body b's rigid-body inertia
-    // (21) and bias force (6) about its own origin. Level by level, the lanes AT depth d take their slot, add
-    // what their children left in theirs (already shifted to this body's origin; fixed order), form U, 1/D, u
-    // (which go to the body record: pass 3 and the row walks read them there), remove the joint's freedom,
-    // shift to the parent's origin and put the result back for the parent. One LDS round trip and one barrier
-    // per level; nothing of this is carried in registers between levels. Level 0 is the base: it only sums.
-    {
-      const TrexDeviceModel *Mi = Mo();
-      const float tau_j = -Mi->damp[bl] * H->st[ST_QD][bl];  // explicit joint damping torque
-      for (int d = maxdepth; d >= 0; d--) {
-        if (depth == d) {
-          float *o = H->u.t.aba[bl];
-          const unsigned ch4 = __float_as_uint(reinterpret_cast<const float *>(&H->body[BREC * bl + 4])[3]);
-          float acc[27];
-          {
-            // own slot and first child's in flight together (most bodies have exactly one child)
-            const int c0 = (int)(ch4 & 255u);
-            const float *c = H->u.t.aba[c0 == 255 ? bl : c0];
-            const float w0 = c0 == 255 ? 0.f : 1.f;
-#pragma unroll
-            for (int k = 0; k < 27; k++) acc[k] = __builtin_fmaf(w0, c[k], o[k]);
-          }
-#pragma unroll 1
-          for (int kc = 1; kc < MAXCH; kc++) {   // further children, fixed order (packed without gaps)
-            const int ch = (int)((ch4 >> (8 * kc)) & 255u);
-            if (ch == 255) break;
-            const float *c = H->u.t.aba[ch];
-#pragma unroll
-            for (int k = 0; k < 27; k++) acc[k] += c[k];
-          }
-          if (d == 0) {
-#pragma unroll
-            for (int k = 0; k < 27; k++) o[k] = acc[k];
-          } else {
-            Sym6 IA;
-            float pA[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++) { IA.A[k] = acc[k]; IA.C[k] = acc[15 + k]; pA[k] = acc[21 + k]; }
-#pragma unroll
-            for (int k = 0; k < 9; k++) IA.B[k] = acc[6 + k];
-            float U[6];   // U = IA S, S = [Sa; 0]
-            sym3_mul(IA.A, Sa, U);
-            U[3] = IA.B[0] * Sa[0] + IA.B[3] * Sa[1] + IA.B[6] * Sa[2];
-            U[4] = IA.B[1] * Sa[0] + IA.B[4] * Sa[1] + IA.B[7] * Sa[2];
-            U[5] = IA.B[2] * Sa[0] + IA.B[5] * Sa[1] + IA.B[8] * Sa[2];
-            const float D = dot3(Sa, U);
-            const float rD = __builtin_amdgcn_rcpf(D);
-#if TREX_ABLATE_EXACT_MATH
-            const float invD = 1.0f / D;
-#else
-            const float invD = rD * __builtin_fmaf(-D, rD, 2.0f);   // v_rcp_f32 + one Newton step (no IEEE division expansion)
-#endif
-            const float u = tau_j - dot3(Sa, pA);
-            float Ud[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++) Ud[k] = U[k] * invD;
-            {
-              float4 *rec = &H->body[BREC * bl];
-              rec[0] = make_float4(Sa[0], Sa[1], Sa[2], invD);
-              rec[2] = make_float4(Ud[0], Ud[1], Ud[2], Ud[3]);
-              rec[3] = make_float4(Ud[4], Ud[5], __int_as_float(psrc + 256 * depth), u * invD);
-            }
-            {   // pa = pA + Ia c + U u / D with Ia c = IA c - U (U.c) / D
-              float Ic[6];
-              sym6_mul(IA, cv, Ic);
-              const float coef = (u - dot6(U, cv)) * invD;
-#pragma unroll
-              for (int k = 0; k < 6; k++) pA[k] += Ic[k] + U[k] * coef;
-            }
-            sym6_rank1_sub(IA, U, Ud);
-            // shift both to the parent's origin (this origin = parent origin + d, d = dpar):
-            //   n' = n + d x f,  B' = B + [d]x C,  A' = A + X^T + X', X = [d]x B^T, X' = [d]x B'^T
-            {
-              cross3_acc(dpar, pA + 3, pA[0], pA[1], pA[2]);
-              const int sidx[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
-#pragma unroll
-              for (int i = 0; i < 3; i++) {   // A_ij += X_ji = (d x row i of B)_j, j >= i
-                float t[3] = {0.f, 0.f, 0.f};
-                if (i == 0) cross3_acc(dpar, IA.B, IA.A[0], IA.A[1], IA.A[2]);
-                else if (i == 1) cross3_acc(dpar, IA.B + 3, t[0], IA.A[3], IA.A[4]);
-                else cross3_acc(dpar, IA.B + 6, t[0], t[1], IA.A[5]);
-              }
-#pragma unroll
-              for (int j = 0; j < 3; j++) {   // column j of [d]x C = d x (column j of C)
-                const float cj[3] = {IA.C[sidx[0][j]], IA.C[sidx[1][j]], IA.C[sidx[2][j]]};
-                cross3_acc(dpar, cj, IA.B[j], IA.B[3 + j], IA.B[6 + j]);
-              }
-#pragma unroll
-              for (int j = 0; j < 3; j++) {   // A_ij += X'_ij = (d x row j of B')_i, i <= j
-                float t[3] = {0.f, 0.f, 0.f};
-                if (j == 0) cross3_acc(dpar, IA.B, IA.A[0], t[1], t[2]);
-                else if (j == 1) cross3_acc(dpar, IA.B + 3, IA.A[1], IA.A[3], t[2]);
-                else cross3_acc(dpar, IA.B + 6, IA.A[2], IA.A[4], IA.A[5]);
-              }
-            }
-#pragma unroll
-            for (int k = 0; k < 6; k++) { o[k] = IA.A[k]; o[15 + k] = IA.C[k]; o[21 + k] = pA[k]; }
-#pragma unroll
-            for (int k = 0; k < 9; k++) o[6 + k] = IA.B[k];
-          }
-        }
-        WSYNC();
-      }
-      if ((PAIR || lt < TL) && !is_joint) {   // base and unused lanes: inert records
-        float4 *rec = &H->body[BREC * bl];
-        rec[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-        rec[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        rec[3] = make_float4(0.f, 0.f, __int_as_float(psrc + 256 * (depth < 0 ? 255 : depth)), 0.f);
-      }
-    }
-    RELANE2();
-    RETREE2();
-    REAXIS2();
-
-    // ---- floating base: a0 = -(IA_0)^-1 pA_0; every lane of a half factors its env's matrix (the same arithmetic on the
-    // same words); lane 0 of the half hands the factor and a0 to the env's own wave
-    float a0h[6];
-    {
-      const float *o = H->u.t.aba[0];
-      Sym6 I0;
-#pragma unroll
-      for (int k = 0; k < 6; k++) { I0.A[k] = o[k]; I0.C[k] = o[15 + k]; }
-#pragma unroll
-      for (int k = 0; k < 9; k++) I0.B[k] = o[6 + k];
-      float p0[6];
-#pragma unroll
-      for (int k = 0; k < 6; k++) p0[k] = -o[21 + k];
-      float full[36];
-      sym6_full(I0, full);
-      Chol6 c;
-      chol6_factor(full, c);
-      chol6_solve(c, p0, a0h);
-      if (bl == 0) {
-        float *x = H->xch + 8;
-#pragma unroll
-        for (int k = 0; k < 15; k++) x[k] = c.l[k];
-#pragma unroll
-        for (int k = 0; k < 6; k++) { x[15 + k] = c.il[k]; x[21 + k] = a0h[k]; }
-      }
-    }
-    // ---- ABA pass 3 (base to tip): accelerations; qdd = (u - U.a) / D = u/D - (U/D).a from the body record
-    float qdd = 0.f;
-    {
-      const float4 q2 = H->body[BREC * bl + 2], q3 = H->body[BREC * bl + 3];
-      const float Ud[6] = {q2.x, q2.y, q2.z, q2.w, q3.x, q3.y};
-      float acc[6];
-#pragma unroll
-      for (int k = 0; k < 6; k++) acc[k] = a0h[k];
-      for (int d = 1; d <= maxdepth; d++) {
-        float pa[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) pa[k] = wshfl(acc[k], psrc + hoff);
-        if (depth == d) {
-          float axd[3];
-          cross3(pa, dpar, axd);   // parent acceleration seen at this body's origin
-#pragma unroll
-          for (int k = 0; k < 3; k++) pa[3 + k] += axd[k];
-#pragma unroll
-          for (int k = 0; k < 6; k++) pa[k] += cv[k];
-          qdd = q3.w - dot6(Ud, pa);
-#pragma unroll
-          for (int k = 0; k < 3; k++) acc[k] = pa[k] + Sa[k] * qdd;
-#pragma unroll
-          for (int k = 3; k < 6; k++) acc[k] = pa[k];
-        }
-      }
-    }
-    // ---- unconstrained joint rates of both envs (each wave forms its own base twist below)
-    {
-      const float vmax = M->prm[TP_MAX_COORD_VEL];
-      const float nqd = is_joint ? fminf(fmaxf(H->st[ST_QD][bl] + qdd * dt, -vmax), vmax) : 0.f;
-      if (PAIR || lt < TL) {
-        reinterpret_cast<float *>(&H->body[BREC * bl + 1])[3] = nqd;
-        H->st[ST_NQD][bl] = nqd;
-      }
-    }
-#undef RELANE2
-#undef REAXIS2
-#undef RETREE2
-      }
-      if (PAIR) __syncthreads(); else WSYNC();      // records (U/D, 1/D, u/D, updated rates), base factor and base acceleration are in LDS
-      if (act) {
-        const float *x = W.xch + 8;      // (every lane reads the same words: LDS broadcast)
-#pragma unroll
-        for (int k = 0; k < 15; k++) I0c.l[k] = uni(x[k]);
-#pragma unroll
-        for (int k = 0; k < 6; k++) { I0c.il[k] = uni(x[15 + k]); a0[k] = uni(x[21 + k]); }
-        const float vmax = M->prm[TP_MAX_COORD_VEL];
-        float wxv[3];
-        cross3(bw, bv, wxv);
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-          nw[k] = uni(fminf(fmaxf(bw[k] + a0[k] * dt, -vmax), vmax));
-          nv[k] = uni(fminf(fmaxf(bv[k] + (a0[3 + k] + wxv[k]) * dt, -vmax), vmax));
-        }
-      }
-    }
-    if (act) {
-    WSYNC();
+    __syncthreads();
     STAMP(4);
     RELANE();
 
@@ -1859,7 +1482,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
       }
     }
     const unsigned lim_mask = (unsigned)__ballot(ldir != 0.f);
-    WSYNC();   // the body records are dead: the z0 stash may overwrite them; so are the inertia slots
+    __syncthreads();   // the body records are dead: the z0 stash may overwrite them; so are the inertia slots
     {
       float *zs = reinterpret_cast<float *>(W.body);
 #pragma unroll
@@ -1871,7 +1494,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
       dc[2] = make_float4(z00[1], z00[2], z00[3], z00[4]);
       dc[3] = make_float4(z00[5], 0.f, 0.f, 0.f);
     }
-    WSYNC();
+    __syncthreads();
     STAMP(5);
     RELANE();
 
@@ -2346,7 +1969,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
         }
       }
     }
-    WSYNC();
+    __syncthreads();
 
     // ---- commit velocities, integrate positions
     if (lt < TL) {
@@ -2385,9 +2008,8 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
     }
     stat_nc = nc;
     stat_imp = nimp;
-    WSYNC();
+    __syncthreads();
     STAMP(8);
-    }   // act (rows, sweeps, integration)
 #undef RELANE
 #undef RETREE
 #undef REAXIS
@@ -2485,8 +2107,6 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
 
 template <bool RESET, bool DEBUG>
 __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) { trex_step_body<RESET, DEBUG, false>(args, (int)blockIdx.x); }
-// two envs per workgroup, the lane-per-body tree phases run once for both (PAIR above); even batch sizes
-__global__ __launch_bounds__(128, 4) void trex_step_pair_kernel(KernelArgs args) { trex_step_body<false, false, false, true>(args, (int)blockIdx.x); }
 // S env-steps per launch (trex_batch_step_many)
 __global__ __launch_bounds__(64, 4) void trex_step_many_kernel(KernelArgs args) { trex_step_body<false, false, true>(args, (int)blockIdx.x); }
 
@@ -2669,11 +2289,7 @@ hipError_t trex_launch_step(const TrexDeviceModel *model, TrexBatchArrays arr, i
 #if TREX_STAMPS   // diagnostic build: the PRODUCT instantiation, stamped (the dump of <false, true> would change its code)
   hipLaunchKernelGGL((trex_step_kernel<false, false>), dim3(n), dim3(64), 0, stream, a);
 #else
-#ifndef TREX_PAIR_LAUNCH
-#define TREX_PAIR_LAUNCH 0
-#endif
   if (debug) hipLaunchKernelGGL((trex_step_kernel<false, true>), dim3(n), dim3(64), 0, stream, a);
-  else if (TREX_PAIR_LAUNCH && (n & 1) == 0) hipLaunchKernelGGL(trex_step_pair_kernel, dim3(n / 2), dim3(128), 0, stream, a);
   else hipLaunchKernelGGL((trex_step_kernel<false, false>), dim3(n), dim3(64), 0, stream, a);
 #endif
   return hipGetLastError();
