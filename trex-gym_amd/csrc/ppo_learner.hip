@@ -4,7 +4,8 @@
 // MLPs, clipped surrogate + clipped value loss, backward, global-norm clip, Adam) costs a stock autograd framework ~90
 // small kernels (0.66 ms per 4096-sample minibatch even replayed from a HIP graph). Here:
 //
-//   learn_grad_kernel   one workgroup = one tile of 32 samples x 2 waves (policy net, value net). Forward exactly as
+//   learn_grad_kernel   one workgroup = one tile of 32 samples of ONE net, 4 waves: a serial-chain wave and three helpers (see
+//                       the kernel). Forward exactly as
 //                       the rollout's act_kernel (transposed MFMA form, activations in registers). The backward pass
 //                       needs two kinds of contractions: over NEURONS (delta^T = W . delta_next^T: the B operand is
 //                       again the lane's own accumulator register, the A operand the LDS copy of W read transposed -
@@ -44,7 +45,7 @@ __host__ __device__ inline LdsLayout make_lds_layout(const Layout &lay) {
   int o = lay.count + 2 * HID;                         // theta + the pad words of the two W2s
   o = (o + 3) & ~3;
   l.X = o; o += TILE * XS;
-  l.buf = o; o += 2 * 2 * HID * TS;      // per wave: ACT [64][TS] + DEL [64][TS]
+  l.buf = o; o += (4 * HID + TILE) * TS;      // parked tiles [row][env]: H1, H2 [64] | D3 [32] | D2, D1 [64]
   l.total = o;
   return l;
 }
@@ -82,25 +83,45 @@ __device__ __forceinline__ float half_sum(float v) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-__global__ __launch_bounds__(128) void learn_grad_kernel(LearnArgs g) {
+// One workgroup = one (tile of 32 samples, net): 4 waves, grid (tiles, 2) = 256 workgroups for a 4096-sample minibatch - the
+// whole chip (round 3: 128 workgroups of 2 waves, half the CUs idle, 44 us). The SERIAL chain - forward, loss, delta3 ->
+// delta2 -> delta1, each needing the one before - is run by waves 0 and 1, each owning one HALF of the 64 neurons of a layer
+// (u = wave: 32 output rows = one MFMA tile; the other half of the previous layer arrives through LDS, where every
+// activation and delta is parked as [row][env] the moment it exists); the weight gradients, which are independent outer
+// products over the samples (grad W = act^T delta: the sample index is the MFMA's k), are taken by waves 2 and 3 as soon as
+// their two operands are parked, beside the chain:
+//   B1: H1 parked | B2: H2 parked | (wave 0: output layer, loss) | B3: D3 / dv parked
+//   delta2 (waves 0, 1)  beside  grad W3 (policy: 2 tiles, waves 2, 3)      | B4: D2 parked
+//   delta1 (waves 0, 1)  beside  grad W2 (4 tiles), grad b2 (waves 2, 3)    | B5: D1 parked
+//   grad W1 (6 tiles, all four waves), grad b1
+// Only this net's parameters are staged (by 256 threads: one trip of loads). Every tile writes its gradient slice to
+// its own row of the partial buffer: no atomics, fixed order in the reduction.
+__global__ __launch_bounds__(256) void learn_grad_kernel(LearnArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, net = tid >> 6;     // wave 0: policy net, wave 1: value net
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, net = blockIdx.y;     // net 0: policy, 1: value
   const int D = g.lay.D, A = g.lay.A;
   const LdsLayout L = make_lds_layout(g.lay);
-  // ---- stage the parameters: one flat loop of 16-byte loads, 16 in flight per thread (three trips for 21 k floats)
+  // ---- stage this net's parameters (the LDS image keeps theta's layout, lds_of; the other net's part stays unwritten):
+  // policy = [pW1, vW1) + logstd, value = [vW1, logstd)
   {
     const float4 *s4 = reinterpret_cast<const float4 *>(g.theta);
-    const int n4 = g.lay.count >> 2;                    // (count is a multiple of 4: policy_common.h)
-    constexpr int UF = 16;
-    for (int i0 = tid; i0 < n4; i0 += 128 * UF) {
+    const int lo4 = (net ? g.lay.vW1 : 0) >> 2, hi4 = (net ? g.lay.logstd : g.lay.vW1) >> 2;
+    const int ls4 = g.lay.logstd >> 2, le4 = g.lay.count >> 2;
+    const int n4 = (hi4 - lo4) + (net ? 0 : le4 - ls4);
+    constexpr int UF = 12;                               // 2 670 float4s by 256 threads: one trip
+    for (int i0 = tid; i0 < n4; i0 += 256 * UF) {
       float4 t[UF];
-#pragma unroll
-      for (int u = 0; u < UF; u++) { const int i = i0 + 128 * u; t[u] = s4[i < n4 ? i : 0]; }
+      int src[UF];
 #pragma unroll
       for (int u = 0; u < UF; u++) {
-        const int i = i0 + 128 * u;
-        if (i < n4) {
-          float *d = lds + lds_of(g.lay, 4 * i);
+        const int i = i0 + 256 * u;
+        src[u] = i < hi4 - lo4 ? lo4 + i : ls4 + (i - (hi4 - lo4));
+        t[u] = s4[i < n4 ? src[u] : lo4];
+      }
+#pragma unroll
+      for (int u = 0; u < UF; u++) {
+        if (i0 + 256 * u < n4) {
+          float *d = lds + lds_of(g.lay, 4 * src[u]);
           d[0] = t[u].x; d[1] = t[u].y; d[2] = t[u].z; d[3] = t[u].w;
         }
       }
@@ -110,297 +131,273 @@ __global__ __launch_bounds__(128) void learn_grad_kernel(LearnArgs g) {
   float *X = lds + L.X;
   constexpr int XC = 96;                                  // columns of X that the weight-gradient tiles read (3 x 32)
   {
-    // the tile's sample indices: ONE trip (they used to be fetched in front of every observation load: two dependent
-    // trips per batch of four loads, twelve in all)
     __shared__ long long tile_rows[TILE];
     if (tid < TILE) tile_rows[tid] = s0 + tid < g.mb ? g.perm[g.first + s0 + tid] : -1;
     __syncthreads();
-    constexpr int UX = 12;                                // TILE * XC / 128 = 24 elements per thread: two trips
-    for (int idx0 = tid; idx0 < TILE * XC; idx0 += 128 * UX) {
+    constexpr int UX = 12;                                // TILE * XC / 256 = 12 elements per thread: one trip
+    for (int idx0 = tid; idx0 < TILE * XC; idx0 += 256 * UX) {
       float raw[UX];
 #pragma unroll
       for (int u = 0; u < UX; u++) {
-        const int idx = idx0 + 128 * u, ii = idx / XC, kk = idx - ii * XC;
-        const long long row = tile_rows[ii];
+        const int idx = idx0 + 256 * u, ii = idx / XC, kk = idx - ii * XC;
+        const long long row = idx < TILE * XC ? tile_rows[ii] : -1;
         raw[u] = (kk < D && row >= 0) ? g.obs[(size_t)row * D + kk] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < UX; u++) {
-        const int idx = idx0 + 128 * u, ii = idx / XC, kk = idx - ii * XC;
-        X[ii * XS + kk] = raw[u];
+        const int idx = idx0 + 256 * u, ii = idx / XC, kk = idx - ii * XC;
+        if (idx < TILE * XC) X[ii * XS + kk] = raw[u];
       }
     }
   }
-  __syncthreads();
   const int col = lane & 31, h = lane >> 5;
   const bool valid = s0 + col < g.mb;
-  const long long sidx = valid ? g.perm[g.first + s0 + col] : 0;
-  // the sample's loss inputs, fetched NOW: their round trips hide behind the forward pass (read where the loss needs
-  // them they cost the kernel 3 us)
+  // the sample's loss inputs (wave 0 runs the output layer and the loss), fetched NOW: their round trips hide behind the staging wait and the forward pass
   f32x16 act_in;
   float adv_in = 0.f, logp0_in = 0.f, val0_in = 0.f, ret_in = 0.f, advm = 0.f, advr = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; r++) act_in[r] = 0.f;
-  if (net == 0) {
+  if (wave == 0) {
+    const long long sidx = valid ? g.perm[g.first + s0 + col] : 0;
+    if (net == 0) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int a = rowmap(r, h);
-      if (a < A && valid) act_in[r] = g.act[(size_t)sidx * A + a];
+      for (int r = 0; r < 16; r++) {
+        const int a = rowmap(r, h);
+        if (a < A && valid) act_in[r] = g.act[(size_t)sidx * A + a];
+      }
+      if (valid) { adv_in = g.adv[sidx]; logp0_in = g.logp0[sidx]; }
+      advm = g.adv_stats[0]; advr = g.adv_stats[1];
+    } else if (valid) {
+      val0_in = g.val0[sidx]; ret_in = g.ret[sidx];
     }
-    if (valid) { adv_in = g.adv[sidx]; logp0_in = g.logp0[sidx]; }
-    advm = g.adv_stats[0]; advr = g.adv_stats[1];
-  } else if (valid) {
-    val0_in = g.val0[sidx]; ret_in = g.ret[sidx];
   }
+  __syncthreads();
   const float *W1 = lds + lds_of(g.lay, net ? g.lay.vW1 : g.lay.pW1), *b1 = lds + lds_of(g.lay, net ? g.lay.vb1 : g.lay.pb1);
   const float *W2 = lds + lds_of(g.lay, net ? g.lay.vW2 : g.lay.pW2), *b2 = lds + lds_of(g.lay, net ? g.lay.vb2 : g.lay.pb2);
   const float *W3 = lds + lds_of(g.lay, net ? g.lay.vW3 : g.lay.pW3), *b3 = lds + lds_of(g.lay, net ? g.lay.vb3 : g.lay.pb3);
-  float *ACT = lds + L.buf + net * 2 * HID * TS, *DEL = ACT + HID * TS;
+  // parked tiles, [row][env] with a row stride of TS words: H1, H2 (activations), D3, D2, D1 (deltas); DV = D3 (value net: dv[env])
+  float *H1 = lds + L.buf, *H2 = H1 + HID * TS, *D3 = H2 + HID * TS, *D2 = D3 + TILE * TS, *D1 = D2 + HID * TS;
   float *out = g.partial + (size_t)blockIdx.x * g.stride;
   const float inv_mb = 1.0f / (float)g.mb;
   const int Dp8 = (D + 7) & ~7;     // (<= XC: the host entry refuses obs_dim > 96)
-  // ================================================================ forward
-  f32x16 h1[2], h2[2];
+  const int oW2 = net ? g.lay.vW2 : g.lay.pW2, ob2 = net ? g.lay.vb2 : g.lay.pb2;
+  const int oW1 = net ? g.lay.vW1 : g.lay.pW1, ob1 = net ? g.lay.vb1 : g.lay.pb1;
+  // one 32 x 32 tile of a weight gradient: grad[(32 u + row)][32 v + col] = sum_env Pa[(32 u + row)][env] Pb[(32 v + col)][env]
+  // (Pa, Pb parked as [row][env], stride sa / sb; for grad W1 Pa is the observation tile, [env][column])
+  auto wgrad = [&](const float *Pa, int sa_row, int sa_env, const float *Pb, int ofs, int ldw, int rows, int cols) {
+    f32x16 acc;
 #pragma unroll
-  for (int u = 0; u < 2; u++) {
-#pragma unroll
-    for (int r = 0; r < 16; r++) h1[u][r] = b1[32 * u + rowmap(r, h)];
-  }
-  for (int k0 = 0; k0 < Dp8; k0 += 8) {                // four k-steps per trip (policy_step.hip, act_kernel)
-    float a0[4], a1[4], b[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int k = k0 + 2 * j + h;
-      b[j] = X[col * XS + k];                          // (zero from column D on; XC = 96 columns are staged)
-      const int kc = k < D ? k : D - 1;
-      a0[j] = W1[kc * HID + col]; a1[j] = W1[kc * HID + 32 + col];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      h1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b[j], h1[0], 0, 0, 0);
-      h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b[j], h1[1], 0, 0, 0);
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < 2; u++) {
-#pragma unroll
-    for (int r = 0; r < 16; r++) h1[u][r] = tanh_fast(h1[u][r]);
-  }
-#pragma unroll
-  for (int u = 0; u < 2; u++) {
-#pragma unroll
-    for (int r = 0; r < 16; r++) h2[u][r] = b2[32 * u + rowmap(r, h)];
-  }
-#pragma unroll
-  for (int t = 0; t < 2; t++) {
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
 #pragma unroll
     for (int s = 0; s < 16; s++) {
-      const int k = 32 * t + rowmap(s, h);
-#pragma unroll
-      for (int u = 0; u < 2; u++) h2[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(W2[k * W2S + 32 * u + col], h1[t][s], h2[u], 0, 0, 0);
+      const int env = 2 * s + h;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Pa[col * sa_row + env * sa_env], Pb[col * TS + env], acc, 0, 0, 0);
     }
+    if (col < cols) {
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        if (rowmap(r, h) < rows) out[ofs + rowmap(r, h) * ldw + col] = acc[r];
+    }
+  };
+  // sum over the 32 envs of row `lane` of a parked tile (bias gradients), fixed order
+  auto row_sum = [&](const float *P) {
+    float t = 0.f;
+#pragma unroll
+    for (int e = 0; e < TILE; e++) t += P[lane * TS + e];
+    return t;
+  };
+  const int u = wave & 1;                  // chain waves: the half of the neurons this wave owns
+  const bool chain = wave < 2;
+  f32x16 h1o, h2o, d2o, d3;                // own halves: rows 32 u + rowmap(r, h) of h1, h2, d2; wave 0: d3 (policy)
+  float dv = 0.f;                          // value net: dL/dv of this lane's env
+  // ================================================================ forward, layer 1 (own half)
+  if (chain) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) h1o[r] = b1[32 * u + rowmap(r, h)];
+    for (int k0 = 0; k0 < Dp8; k0 += 8) {                // four k-steps per trip (policy_step.hip, act_kernel)
+      float a[4], b[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int k = k0 + 2 * j + h;
+        b[j] = X[col * XS + k];                          // (zero from column D on; XC = 96 columns are staged)
+        const int kc = k < D ? k : D - 1;
+        a[j] = W1[kc * HID + 32 * u + col];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) h1o = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], h1o, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) { h1o[r] = tanh_fast(h1o[r]); H1[(32 * u + rowmap(r, h)) * TS + col] = h1o[r]; }
   }
+  __syncthreads();     // ---- B1: H1 is parked
+  // ================================================================ forward, layer 2 (own half; k ascending: t = 0, 1)
+  if (chain) {
 #pragma unroll
-  for (int u = 0; u < 2; u++) {
-#pragma unroll
-    for (int r = 0; r < 16; r++) h2[u][r] = tanh_fast(h2[u][r]);
-  }
-  // ================================================================ output layer, loss, output-layer gradients
-  f32x16 d2[2];      // dL / d(pre-activation of layer 2), transposed tile layout
-  if (net == 0) {
-    f32x16 mu;
-#pragma unroll
-    for (int r = 0; r < 16; r++) { const int a = rowmap(r, h); mu[r] = a < A ? b3[a] : 0.f; }
+    for (int r = 0; r < 16; r++) h2o[r] = b2[32 * u + rowmap(r, h)];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
+      if (t == u) {
 #pragma unroll
-      for (int s = 0; s < 16; s++) {
-        const int k = 32 * t + rowmap(s, h);
-        mu = __builtin_amdgcn_mfma_f32_32x32x2f32(col < A ? W3[k * A + col] : 0.f, h2[t][s], mu, 0, 0, 0);
+        for (int s = 0; s < 16; s++)
+          h2o = __builtin_amdgcn_mfma_f32_32x32x2f32(W2[(32 * t + rowmap(s, h)) * W2S + 32 * u + col], h1o[s], h2o, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 16; s++)
+          h2o = __builtin_amdgcn_mfma_f32_32x32x2f32(W2[(32 * t + rowmap(s, h)) * W2S + 32 * u + col], H1[(32 * t + rowmap(s, h)) * TS + col], h2o, 0, 0, 0);
       }
     }
-    const float *ls = lds + lds_of(g.lay, g.lay.logstd);
-    f32x16 z, isd;
-    float zz = 0.f, sum_ls = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int a = rowmap(r, h);
-      z[r] = 0.f; isd[r] = 0.f;
-      if (a < A) {
-        const float l = ls[a];
-        sum_ls += l;
-        isd[r] = expf(-l);
-        const float ac = valid ? act_in[r] : mu[r];
-        z[r] = (ac - mu[r]) * isd[r];
-        zz = __builtin_fmaf(z[r], z[r], zz);
+    for (int r = 0; r < 16; r++) { h2o[r] = tanh_fast(h2o[r]); H2[(32 * u + rowmap(r, h)) * TS + col] = h2o[r]; }
+  }
+  __syncthreads();     // ---- B2: H2 is parked
+  // ================================================================ wave 0: output layer, loss, delta3 (policy) / dv (value)
+  if (wave == 0) {
+    if (net == 0) {
+      f32x16 mu;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { const int a = rowmap(r, h); mu[r] = a < A ? b3[a] : 0.f; }
+#pragma unroll
+      for (int s = 0; s < 16; s++)
+        mu = __builtin_amdgcn_mfma_f32_32x32x2f32(col < A ? W3[rowmap(s, h) * A + col] : 0.f, h2o[s], mu, 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 16; s++)
+        mu = __builtin_amdgcn_mfma_f32_32x32x2f32(col < A ? W3[(32 + rowmap(s, h)) * A + col] : 0.f, H2[(32 + rowmap(s, h)) * TS + col], mu, 0, 0, 0);
+      const float *ls = lds + lds_of(g.lay, g.lay.logstd);
+      f32x16 z, isd;
+      float zz = 0.f, sum_ls = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int a = rowmap(r, h);
+        z[r] = 0.f; isd[r] = 0.f;
+        if (a < A) {
+          const float l = ls[a];
+          sum_ls += l;
+          isd[r] = expf(-l);
+          const float ac = valid ? act_in[r] : mu[r];
+          z[r] = (ac - mu[r]) * isd[r];
+          zz = __builtin_fmaf(z[r], z[r], zz);
+        }
       }
+      zz += __shfl_xor(zz, 32, 64);
+      sum_ls += __shfl_xor(sum_ls, 32, 64);
+      const float logp = -0.5f * zz - sum_ls - 0.5f * LOG_2PI * (float)A;
+      const float an = valid ? (adv_in - advm) * advr : 0.f;
+      const float ratio = valid ? expf(logp - logp0_in) : 1.f;
+      const float rc = fminf(fmaxf(ratio, 1.f - g.cliprange), 1.f + g.cliprange);
+      const float l1 = -an * ratio, l2 = -an * rc;
+      const bool through = l1 >= l2 || rc == ratio;      // the branch of max() that carries a gradient w.r.t. ratio
+      const float dlogp = valid && through ? -an * ratio * inv_mb : 0.f;     // dL/dlogp = dL/dratio * ratio
+      // L_pg = mean(max(-a r, -a clip(r))), r = exp(logp - logp0): dL/dlogp = (-a) r / mb on the live branch;
+      // dlogp/dmu = z / sd; dlogp/dlogstd = z^2 - 1
+      float pg = valid ? fmaxf(l1, l2) : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int a = rowmap(r, h);
+        d3[r] = dlogp * z[r] * isd[r];
+        D3[rowmap(r, h) * TS + col] = d3[r];
+        const float gl = half_sum(a < A ? dlogp * (z[r] * z[r] - 1.f) : 0.f);      // d/dlogstd, summed over the tile's samples
+        const float gb = half_sum(d3[r]);
+        if (col == 0 && a < A) { out[g.lay.logstd + a] = gl; out[g.lay.pb3 + a] = gb; }
+      }
+      pg = half_sum(h == 0 ? pg : 0.f);
+      if (lane == 0) out[g.stride - 4] = pg;              // sum of the tile's surrogate terms (the mean is taken later)
+    } else {
+      // ---- value head: v = w . h2 + b (k ascending); clipped value loss; its gradients are rank-1 in the sample
+      float v = 0.f;
+#pragma unroll
+      for (int s = 0; s < 16; s++) v = __builtin_fmaf(h2o[s], W3[rowmap(s, h)], v);
+#pragma unroll
+      for (int s = 0; s < 16; s++) v = __builtin_fmaf(H2[(32 + rowmap(s, h)) * TS + col], W3[32 + rowmap(s, h)], v);
+      v += __shfl_xor(v, 32, 64);
+      v += b3[0];
+      const float v0 = valid ? val0_in : v, rt = valid ? ret_in : v;
+      const float dvc = fminf(fmaxf(v - v0, -g.cliprange), g.cliprange);
+      const float vclip = v0 + dvc;
+      const float e1 = (v - rt) * (v - rt), e2 = (vclip - rt) * (vclip - rt);
+      // 0.5 mean(max(e1, e2)): gradient (v - R) on the unclipped branch, (vclip - R) [clip inactive] on the other
+      dv = e1 >= e2 ? (v - rt) : ((dvc == v - v0) ? (vclip - rt) : 0.f);
+      dv = valid ? g.vf_coef * dv * inv_mb : 0.f;
+      const float vl = half_sum((valid && h == 0) ? 0.5f * fmaxf(e1, e2) : 0.f);
+      const float gb = half_sum(h == 0 ? dv : 0.f);
+      if (lane == 0) { out[g.stride - 3] = vl; out[g.lay.vb3] = gb; }
+      if (h == 0) D3[col] = dv;                           // DV[env] for wave 1
     }
-    zz += __shfl_xor(zz, 32, 64);
-    sum_ls += __shfl_xor(sum_ls, 32, 64);
-    const float logp = -0.5f * zz - sum_ls - 0.5f * LOG_2PI * (float)A;
-    const float an = valid ? (adv_in - advm) * advr : 0.f;
-    const float ratio = valid ? expf(logp - logp0_in) : 1.f;
-    const float rc = fminf(fmaxf(ratio, 1.f - g.cliprange), 1.f + g.cliprange);
-    const float l1 = -an * ratio, l2 = -an * rc;
-    const bool through = l1 >= l2 || rc == ratio;      // the branch of max() that carries a gradient w.r.t. ratio
-    const float dlogp = valid && through ? -an * ratio * inv_mb : 0.f;     // dL/dlogp = dL/dratio * ratio
-    // dL/dmu = -dlogp ... careful with signs: L_pg = mean(max(-a r, -a clip(r))), r = exp(logp - logp0):
-    //   dL/dlogp = (-a) r / mb on the live branch; dlogp/dmu = z / sd; dlogp/dlogstd = z^2 - 1
-    f32x16 d3;
-    float pg = valid ? fmaxf(l1, l2) : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int a = rowmap(r, h);
-      d3[r] = dlogp * z[r] * isd[r];
-      const float gl = half_sum(a < A ? dlogp * (z[r] * z[r] - 1.f) : 0.f);      // d/dlogstd, summed over the tile's samples
-      const float gb = half_sum(d3[r]);
-      if (col == 0 && a < A) { out[g.lay.logstd + a] = gl; out[g.lay.pb3 + a] = gb; }
-    }
-    pg = half_sum(h == 0 ? pg : 0.f);
-    if (lane == 0) out[g.stride - 4] = pg;              // sum of the tile's surrogate terms (the mean is taken later)
-    // ---- grad W3[n2][a] = sum_env h2[env][n2] d3[env][a]: both tiles through the wave's LDS buffer, env becomes k
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-#pragma unroll
-      for (int r = 0; r < 16; r++) ACT[(32 * u + rowmap(r, h)) * TS + col] = h2[u][r];
-    }
-#pragma unroll
-    for (int r = 0; r < 16; r++) DEL[rowmap(r, h) * TS + col] = d3[r];
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
+  }
+  __syncthreads();     // ---- B3: D3 (policy) / dv (value) is parked
+  // ================================================================ delta of layer 2 (own half)  |  grad W3
+  if (chain) {
+    if (net == 0) {
+      // d2^T = (W3 d3^T) * (1 - h2^2); k = action = rowmap(s, h): B is d3 - wave 0's own registers, wave 1 reads the parked tile
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[r] = 0.f;
+      if (wave == 0) {
 #pragma unroll
-      for (int s = 0; s < 16; s++) {
-        const int env = 2 * s + h;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ACT[(32 * u + col) * TS + env], DEL[col * TS + env], acc, 0, 0, 0);
-      }
-      if (col < A) {
+        for (int s = 0; s < 16; s++) {
+          const int a = rowmap(s, h);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a < A ? W3[(32 * u + col) * A + a] : 0.f, d3[s], acc, 0, 0, 0);
+        }
+      } else {
 #pragma unroll
-        for (int r = 0; r < 16; r++) out[g.lay.pW3 + (32 * u + rowmap(r, h)) * A + col] = acc[r];
-      }
-    }
-    // ---- delta of layer 2: d2^T = (W3 d3^T) * (1 - h2^2); k = action = rowmap(s, h): B is the lane's own register
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-      f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[r] = 0.f;
-#pragma unroll
-      for (int s = 0; s < 16; s++) {
-        const int a = rowmap(s, h);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a < A ? W3[(32 * u + col) * A + a] : 0.f, d3[s], acc, 0, 0, 0);
+        for (int s = 0; s < 16; s++) {
+          const int a = rowmap(s, h);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a < A ? W3[(32 * u + col) * A + a] : 0.f, D3[a * TS + col], acc, 0, 0, 0);
+        }
       }
 #pragma unroll
-      for (int r = 0; r < 16; r++) d2[u][r] = acc[r] * (1.f - h2[u][r] * h2[u][r]);
-    }
-  } else {
-    // ---- value head: v = w . h2 + b; clipped value loss; its gradients are rank-1 in the sample
-    float v = 0.f;
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-#pragma unroll
-      for (int s = 0; s < 16; s++) v = __builtin_fmaf(h2[t][s], W3[32 * t + rowmap(s, h)], v);
-    }
-    v += __shfl_xor(v, 32, 64);
-    v += b3[0];
-    const float v0 = valid ? val0_in : v, rt = valid ? ret_in : v;
-    const float dvc = fminf(fmaxf(v - v0, -g.cliprange), g.cliprange);
-    const float vclip = v0 + dvc;
-    const float e1 = (v - rt) * (v - rt), e2 = (vclip - rt) * (vclip - rt);
-    // 0.5 mean(max(e1, e2)): gradient (v - R) on the unclipped branch, (vclip - R) [clip inactive] on the other
-    float dv = e1 >= e2 ? (v - rt) : ((dvc == v - v0) ? (vclip - rt) : 0.f);
-    dv = valid ? g.vf_coef * dv * inv_mb : 0.f;
-    const float vl = half_sum((valid && h == 0) ? 0.5f * fmaxf(e1, e2) : 0.f);
-    const float gb = half_sum(h == 0 ? dv : 0.f);
-    if (lane == 0) { out[g.stride - 3] = vl; out[g.lay.vb3] = gb; }
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
+      for (int r = 0; r < 16; r++) d2o[r] = acc[r] * (1.f - h2o[r] * h2o[r]);
+    } else {
+      if (wave == 1) dv = D3[col];
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int k = 32 * u + rowmap(r, h);
-        const float gw = half_sum(h2[u][r] * dv);            // grad W3[k] = sum_env h2[env][k] dv[env]
+        const float gw = half_sum(h2o[r] * dv);                // grad W3[k] = sum_env h2[env][k] dv[env]
         if (col == 0) out[g.lay.vW3 + k] = gw;
-        d2[u][r] = W3[k] * dv * (1.f - h2[u][r] * h2[u][r]);
+        d2o[r] = W3[k] * dv * (1.f - h2o[r] * h2o[r]);
       }
     }
+#pragma unroll
+    for (int r = 0; r < 16; r++) D2[(32 * u + rowmap(r, h)) * TS + col] = d2o[r];
+  } else if (net == 0) {
+    // ---- grad W3[n2][a] = sum_env h2[env][n2] d3[env][a]: row tile (wave - 2) of H2 against D3
+    wgrad(H2 + 32 * (wave - 2) * TS, TS, 1, D3, g.lay.pW3 + 32 * (wave - 2) * A, A, 32, A);
   }
-  // ================================================================ layers 2 and 1, the same for both nets
-  const int oW2 = net ? g.lay.vW2 : g.lay.pW2, ob2 = net ? g.lay.vb2 : g.lay.pb2;
-  const int oW1 = net ? g.lay.vW1 : g.lay.pW1, ob1 = net ? g.lay.vb1 : g.lay.pb1;
-  // ---- grad b2, grad W2[n1][n2] = sum_env h1[env][n1] d2[env][n2]
-#pragma unroll
-  for (int u = 0; u < 2; u++) {
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const float gb = half_sum(d2[u][r]);
-      if (col == 0) out[ob2 + 32 * u + rowmap(r, h)] = gb;
-      ACT[(32 * u + rowmap(r, h)) * TS + col] = h1[u][r];
-      DEL[(32 * u + rowmap(r, h)) * TS + col] = d2[u][r];
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < 2; u++) {
-#pragma unroll
-    for (int v = 0; v < 2; v++) {
-      f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[r] = 0.f;
-#pragma unroll
-      for (int s = 0; s < 16; s++) {
-        const int env = 2 * s + h;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ACT[(32 * u + col) * TS + env], DEL[(32 * v + col) * TS + env], acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; r++) out[oW2 + (32 * u + rowmap(r, h)) * HID + 32 * v + col] = acc[r];
-    }
-  }
-  // ---- delta of layer 1: d1^T = (W2 d2^T) * (1 - h1^2); W2 read transposed (row stride 65: conflict-free)
-  f32x16 d1[2];
-#pragma unroll
-  for (int u = 0; u < 2; u++) {
+  __syncthreads();     // ---- B4: D2 is parked
+  // ================================================================ delta of layer 1 (own half)  |  grad W2, grad b2
+  if (chain) {
+    // d1^T = (W2 d2^T) * (1 - h1^2); W2 read transposed (row stride 65: conflict-free); k ascending: t = 0, 1
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; t++) {
+      if (t == u) {
 #pragma unroll
-      for (int s = 0; s < 16; s++)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W2[(32 * u + col) * W2S + 32 * t + rowmap(s, h)], d2[t][s], acc, 0, 0, 0);
-    }
+        for (int s = 0; s < 16; s++)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W2[(32 * u + col) * W2S + 32 * t + rowmap(s, h)], d2o[s], acc, 0, 0, 0);
+      } else {
 #pragma unroll
-    for (int r = 0; r < 16; r++) d1[u][r] = acc[r] * (1.f - h1[u][r] * h1[u][r]);
-  }
-  // ---- grad b1, grad W1[k][n1] = sum_env x[env][k] d1[env][n1]
-#pragma unroll
-  for (int u = 0; u < 2; u++) {
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const float gb = half_sum(d1[u][r]);
-      if (col == 0) out[ob1 + 32 * u + rowmap(r, h)] = gb;
-      DEL[(32 * u + rowmap(r, h)) * TS + col] = d1[u][r];
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < 3; q++) {
-#pragma unroll
-    for (int v = 0; v < 2; v++) {
-      f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[r] = 0.f;
-#pragma unroll
-      for (int s = 0; s < 16; s++) {
-        const int env = 2 * s + h;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(X[env * XS + 32 * q + col], DEL[(32 * v + col) * TS + env], acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int k = 32 * q + rowmap(r, h);
-        if (k < D) out[oW1 + k * HID + 32 * v + col] = acc[r];
+        for (int s = 0; s < 16; s++)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W2[(32 * u + col) * W2S + 32 * t + rowmap(s, h)], D2[(32 * t + rowmap(s, h)) * TS + col], acc, 0, 0, 0);
       }
     }
+#pragma unroll
+    for (int r = 0; r < 16; r++) D1[(32 * u + rowmap(r, h)) * TS + col] = acc[r] * (1.f - h1o[r] * h1o[r]);
+  } else {
+    // ---- grad W2[n1][n2] = sum_env h1[env][n1] d2[env][n2]: four tiles (uu, v), two per helper wave; grad b2 = row sums of D2
+    for (int t = wave - 2; t < 4; t += 2) {
+      const int uu = t >> 1, v = t & 1;
+      wgrad(H1 + 32 * uu * TS, TS, 1, D2 + 32 * v * TS, oW2 + 32 * uu * HID + 32 * v, HID, 32, 32);
+    }
+    if (wave == 3) out[ob2 + lane] = row_sum(D2);
   }
+  __syncthreads();     // ---- B5: D1 is parked
+  // ---- grad W1[k][n1] = sum_env x[env][k] d1[env][n1]: six tiles (q, v) over the four waves; grad b1 = row sums of D1
+  for (int t = wave; t < 6; t += 4) {
+    const int q = t >> 1, v = t & 1;
+    wgrad(X + 32 * q, 1, XS, D1 + 32 * v * TS, oW1 + 32 * q * HID + 32 * v, HID, D - 32 * q, 32);
+  }
+  if (wave == 2) out[ob1 + lane] = row_sum(D1);
 }
 
 // ---------------------------------------------------------------- advantage statistics of every minibatch of an epoch
@@ -442,13 +439,15 @@ struct ApplyArgs {
   float ent_coef, lr, b1, b2, eps, max_norm, inv_mb;
 };
 
-// Two launches (no last-workgroup serial tail: a single workgroup updating 21 k parameters in six dependent trips
+// Two launches (measured in round 4 and not kept: ONE launch with a grid barrier between the column sums and Adam - arrival
+// count + generation word, all 83 workgroups resident - took 21 us against 4.8 + 5.0; and no last-workgroup serial tail: a single workgroup updating 21 k parameters in six dependent trips
 // behind two device-scope fences was most of the old single launch's 31 us):
 //   learn_reduce_kernel  one float4 column of the partial rows per thread, 8 tile groups per workgroup (two trips of 8
 //                        loads), groups added in order -> grad, + the workgroup's squared norm; workgroup 0 advances
 //                        the Adam step count
 //   learn_adam_kernel    every workgroup sums the squared norms (workgroup order), clips and updates its 256 float4s
 constexpr int AP_COLS = 64, AP_GROUPS = 8;
+constexpr int LR_SLOT = 4095;          // learn_red[LR_SLOT]: the Adam step size of the current minibatch step (the buffer holds 4096 doubles)
 __global__ __launch_bounds__(AP_COLS * AP_GROUPS) void learn_reduce_kernel(ApplyArgs g) {
   __shared__ float4 part[AP_GROUPS][AP_COLS];
   __shared__ double wred[AP_COLS * AP_GROUPS / 64];
@@ -497,38 +496,41 @@ __global__ __launch_bounds__(AP_COLS * AP_GROUPS) void learn_reduce_kernel(Apply
     double t = 0.0;
     for (int w = 0; w < AP_COLS * AP_GROUPS / 64; w++) t += wred[w];
     g.red[blockIdx.x] = t;
-    if (blockIdx.x == 0) *g.step = *g.step + 1;        // (read by the Adam launch that follows on the stream)
+    if (blockIdx.x == 0) {
+      // the Adam step count and TensorFlow's step size for it, formed HERE, off the Adam launch's critical path (two double
+      // pow() by one thread cost that launch about a microsecond): lr_t = lr sqrt(1 - b2^t) / (1 - b1^t)
+      const int st = *g.step + 1;
+      *g.step = st;
+      g.red[LR_SLOT] = (double)g.lr * sqrt(1.0 - pow((double)g.b2, (double)st)) / (1.0 - pow((double)g.b1, (double)st));
+    }
   }
 }
 
 __global__ __launch_bounds__(256) void learn_adam_kernel(ApplyArgs g, int reduce_groups) {
-  __shared__ double rsh[256];
-  __shared__ float lr_sh, scale_sh;
+  __shared__ double rsh[4];
   const int tid = threadIdx.x;
-  rsh[tid] = tid < reduce_groups ? g.red[tid] : 0.0;
+  // this thread's parameters, fetched before the norm is known
+  const int i = blockIdx.x * 256 + tid, P4 = g.count >> 2;
+  float4 *t4 = reinterpret_cast<float4 *>(g.theta), *m4 = reinterpret_cast<float4 *>(g.m), *v4 = reinterpret_cast<float4 *>(g.v);
+  float4 gv = make_float4(0.f, 0.f, 0.f, 0.f), tv = gv, mv = gv, vv = gv;
+  if (i < P4) { gv = reinterpret_cast<const float4 *>(g.grad)[i]; tv = t4[i]; mv = m4[i]; vv = v4[i]; }
+  // the global norm: the workgroups' squared norms added in a FIXED tree (the same in every workgroup: deterministic) -
+  // each thread one or more partials, butterfly inside the wave, the four waves in order
+  double t = 0.0;
+  for (int w = tid; w < reduce_groups; w += 256) t += g.red[w];
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+  if ((tid & 63) == 0) rsh[tid >> 6] = t;
   __syncthreads();
-  if (tid == 0) {
-    double t = 0.0;
-    for (int w = 0; w < reduce_groups && w < 256; w++) t += rsh[w];       // workgroup order: the same sum in every workgroup
-    for (int w = 256; w < reduce_groups; w++) t += g.red[w];
-    const float norm = (float)sqrt(t);
-    scale_sh = g.max_norm > 0.f ? g.max_norm / fmaxf(norm, g.max_norm) : 1.f;        // tf.clip_by_global_norm
-    const int st = *g.step;
-    lr_sh = (float)((double)g.lr * sqrt(1.0 - pow((double)g.b2, (double)st)) / (1.0 - pow((double)g.b1, (double)st)));
-  }
-  __syncthreads();
-  const float scale = scale_sh, lr_t = lr_sh;
+  const float norm = (float)sqrt(((rsh[0] + rsh[1]) + rsh[2]) + rsh[3]);
+  const float scale = g.max_norm > 0.f ? g.max_norm / fmaxf(norm, g.max_norm) : 1.f;        // tf.clip_by_global_norm
+  const float lr_t = (float)g.red[LR_SLOT];       // lr sqrt(1 - b2^t) / (1 - b1^t), formed by the reduce launch
   auto upd = [&](float gr, float &mi, float &vi, float &th) {
     const float gi = gr * scale;
     mi = g.b1 * mi + (1.f - g.b1) * gi;
     vi = g.b2 * vi + (1.f - g.b2) * gi * gi;
     th -= lr_t * mi / (sqrtf(vi) + g.eps);
   };
-  const int i = blockIdx.x * 256 + tid, P4 = g.count >> 2;
   if (i < P4) {
-    float4 *t4 = reinterpret_cast<float4 *>(g.theta), *m4 = reinterpret_cast<float4 *>(g.m), *v4 = reinterpret_cast<float4 *>(g.v);
-    const float4 gv = reinterpret_cast<const float4 *>(g.grad)[i];
-    float4 tv = t4[i], mv = m4[i], vv = v4[i];
     upd(gv.x, mv.x, vv.x, tv.x); upd(gv.y, mv.y, vv.y, tv.y); upd(gv.z, mv.z, vv.z, tv.z); upd(gv.w, mv.w, vv.w, tv.w);
     t4[i] = tv; m4[i] = mv; v4[i] = vv;
   }
@@ -603,7 +605,7 @@ int trex_policy_minibatch_step(TrexPolicy *p, float *theta_dev, float *grad_dev,
   const LdsLayout L = make_lds_layout(p->lay);
   LearnArgs a{theta_dev, obs_dev, act_dev, logp_dev, val_dev, adv_dev, ret_dev, reinterpret_cast<const long long *>(perm_dev),
               adv_stats_dev, p->grad_partial, first, mb, stride, cliprange, vf_coef, p->lay};
-  hipLaunchKernelGGL(learn_grad_kernel, dim3(tiles), dim3(128), (size_t)L.total * sizeof(float), (hipStream_t)stream, a);
+  hipLaunchKernelGGL(learn_grad_kernel, dim3(tiles, 2), dim3(256), (size_t)L.total * sizeof(float), (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
   ApplyArgs b{p->grad_partial, theta_dev, grad_dev, m_dev, v_dev, loss_sums_dev, p->learn_red, p->learn_counter, p->adam_step,
               tiles, stride, p->lay.count, p->lay.logstd, p->A, ent_coef, lr, beta1, beta2, eps, max_grad_norm, 1.0f / (float)mb};
