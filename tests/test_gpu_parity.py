@@ -3,15 +3,19 @@
 committed golden rollouts, and - at BASELINE's full 4096 envs - through size-independent properties.
 
 Stated tolerances (f32 kernel vs f64 oracle; PGS amplifies rounding in contact):
-  one env-step from an identical state: |dq| <= 1e-4 rad, |dqd| <= 5e-3 * max(1, |qd|_inf),
-  motor torque <= 5e-3 * max|tau| over the unsaturated joints (+1 N m), saturated joints saturated alike,
+  one env-step from an identical state: |dq| <= 1e-4 rad, |dqd| <= 3e-3 * max(1, |qd|_inf),
+  motor torque <= 3e-3 * max|tau| over the unsaturated joints (+1 N m), saturated joints saturated alike,
   reward <= 2e-3 relative (+1e-3, + a tenth of what the qd / tau tolerances allow in the energy term)
   contact-free trajectories (8..25 steps): |dq| <= 1e-4, |dqd| <= 5e-4 * max(1, |qd|_inf)
-Measured over 252 states, 152 of them in contact (scripts/parity_stats.py on the round-3 kernel,
-profiles/r03_parity_stats.txt): max |dq| 3.4e-5, |dqd| 1.43e-3, torque 1.61e-3, reward 5.5e-4 (medians 1e-7 .. 2e-6);
-airborne states 2e-7 .. 7e-6. Head-room against the 5e-3 rate / torque tolerances: 3.5x. (Round 1's kernel had
-7.7e-4 / 9.0e-4; the round-2 rewrite of the solver - residual form, impulse-shifted bounds - doubled the worst case;
-exact-arithmetic ablation builds show the v_rsq / v_rcp / series shortcuts are not the cause.)
+  K steps THROUGH contact (K = 5, 10): the kernel separates from the f64 oracle no faster than the oracle's own f32 build does
+  (per state <= 3 x that build's separation + a floor; over the 50 landing states the median ratio is below 1)
+Measured over 252 states, 152 of them in contact (scripts/parity_stats.py, profiles/r03_parity_stats.txt, unchanged by round 4's
+kernel edits - bitwise the same rows): max |dq| 3.4e-5, |dqd| 1.43e-3, torque 1.61e-3, reward 5.5e-4 (medians 1e-7 .. 2e-6);
+airborne states 2e-7 .. 7e-6. 1.5e-3 is the kernel's one-step bound on these states: 60 sweeps over up to 64 coupled rows in
+f32 on ill-conditioned contact states, in a summation order that differs from the oracle's (exact-arithmetic ablation builds
+show the v_rsq / v_rcp / series shortcuts are not the cause; the oracle's OWN f32 build is 2.1e-4 .. 3.2e-3 off its f64 build
+on the landing states, scripts/kstep_separation.py). The rate / torque tolerance was 5e-3 until round 3; it is 3e-3 now: 2x the
+measured bound.
 """
 import os
 
@@ -41,7 +45,7 @@ def assert_step_close(g_obs, o_obs, g_rew=None, o_rew=None, what="", q_atol=1e-4
     J = 25
     assert np.isfinite(g_obs).all(), what
     np.testing.assert_allclose(g_obs[:J], o_obs[:J], atol=q_atol, rtol=0, err_msg=what + " q")
-    np.testing.assert_allclose(g_obs[J:2 * J], o_obs[J:2 * J], atol=loosen * 5e-3 * max(1.0, np.abs(o_obs[J:2 * J]).max()),
+    np.testing.assert_allclose(g_obs[J:2 * J], o_obs[J:2 * J], atol=loosen * 3e-3 * max(1.0, np.abs(o_obs[J:2 * J]).max()),
                                rtol=0, err_msg=what + " qd")
     # motor torque: a joint saturated in the oracle (3e5 N m, trex_robot.py:260) must be saturated with the same sign;
     # the others are compared on the scale of the largest UNsaturated torque (a saturated neighbour must not hide
@@ -51,12 +55,12 @@ def assert_step_close(g_obs, o_obs, g_rew=None, o_rew=None, what="", q_atol=1e-4
     assert np.all(np.abs(gt[sat]) >= 0.999 * 3.0e5) and np.all(np.sign(gt[sat]) == np.sign(ot[sat])), what + " saturated tau"
     if (~sat).any():
         tscale = np.abs(ot[~sat]).max()
-        np.testing.assert_allclose(gt[~sat], ot[~sat], atol=5e-3 * tscale + 1.0, rtol=0, err_msg=what + " tau")
+        np.testing.assert_allclose(gt[~sat], ot[~sat], atol=3e-3 * tscale + 1.0, rtol=0, err_msg=what + " tau")
     if g_rew is not None:
         # reward = -lift - drift - w_e sum|qd tau| (trex_env.py:186-192): 2e-3 relative on the whole, plus what the
         # stated qd / tau tolerances allow in the energy term (w_e = 0.005, the default of every test here)
-        qd_tol = 5e-3 * max(1.0, np.abs(o_obs[J:2 * J]).max())
-        tau_tol = np.where(sat, 1e-3 * 3.0e5, 5e-3 * (np.abs(ot[~sat]).max() if (~sat).any() else 0.0) + 1.0)
+        qd_tol = 3e-3 * max(1.0, np.abs(o_obs[J:2 * J]).max())
+        tau_tol = np.where(sat, 1e-3 * 3.0e5, 3e-3 * (np.abs(ot[~sat]).max() if (~sat).any() else 0.0) + 1.0)
         energy_tol = 0.005 * np.sum(np.abs(o_obs[J:2 * J]) * tau_tol + np.abs(ot) * qd_tol)
         assert abs(g_rew - o_rew) <= 2e-3 * abs(o_rew) + 1e-3 + 0.1 * energy_tol, (what, g_rew, o_rew)
 
@@ -609,8 +613,9 @@ def test_more_touching_bodies_than_contact_rows(model, params):
         orc.set_state(s2, states[t].astype(np.float64))
         o, r, _ = orc.step(s2, q0.astype(np.float64))
         # (4 rows for 7 touching bodies is not a consistent support - the supporting set rotates, the ground force
-        # jitters around 1.2 x the weight, tests/test_oracle_physics.py - and amplifies rounding: 2x the rate tolerance)
-        assert_step_close(obs[t], o, rew[t], r, "budget state %d" % t, loosen=2.0 if budget < 7 else 1.0)
+        # jitters around 1.2 x the weight, tests/test_oracle_physics.py - and amplifies rounding: 1e-2 of the rate scale there,
+        # as before round 4 tightened the general tolerance to 3e-3; measured 7.2e-3 / 2.4)
+        assert_step_close(obs[t], o, rew[t], r, "budget state %d" % t, loosen=10.0 / 3.0 if budget < 7 else 1.0)
         assert cnt[t].item() == len(orc.contacts(s2)[0]) <= budget
         over += cnt[t].item() == budget
     assert over > 5                                   # the budget really was exhausted along the way
@@ -829,4 +834,125 @@ def test_episode_statistics_in_the_infos_of_the_numpy_api():
                 assert infos[i] == {}
     # first episodes are cut short by the staggered ages, the following ones last `limit` steps
     assert [(t, i) for t, i, _ in seen if t < 4] == [(0, 3), (1, 2), (2, 1), (3, 0), (3, 4)]
-    assert all(l == limit for t, i, l in seen if t >= 4) and len(seen) == 5 + 5
+    assert all(l == limit for t, i, l in seen if t >= 4) and len(seen) == 5 + 6       # (env 3 ends a third time at t = 8)
+
+
+@pytest.mark.parametrize("K", [5, 10])
+def test_k_steps_through_contact_separate_no_faster_than_the_f32_oracle(K, oracle64, oracle32, model):
+    """VERDICT r3 item 6a. One-step parity says nothing about how fast the kernel and the f64 oracle drift apart over a few
+    steps of CONTACT (trajectories are chaotic there: any two f32 evaluations separate). The yardstick is the oracle's own
+    f32 build: from the 50 landing states (free fall, impact, standing under noise), K steps of one action sequence on the GPU,
+    on the f64 oracle and on the f32 oracle. Per state the kernel's separation from f64 is at most 3 x the f32 oracle's (+ a
+    floor where both are at rounding level: 2e-5 rad, 1e-4 of the rate scale), and over the 50 states the kernel is the CLOSER
+    of the two (median ratio < 1; measured 0.4 - 0.5, scripts/kstep_separation.py)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "scripts"))
+    from kstep_separation import landing_states, separations
+    states = landing_states(oracle64, model)
+    assert len(states) == 50
+    s = separations(K, states, model, oracle64, oracle32, DEV)
+    dq_g, dq_o, dqd_g, dqd_o = s[:, 0], s[:, 1], s[:, 2], s[:, 3]
+    assert np.all(dq_g <= 3.0 * dq_o + 2e-5), (dq_g - 3.0 * dq_o).max()
+    assert np.all(dqd_g <= 3.0 * dqd_o + 1e-4), (dqd_g - 3.0 * dqd_o).max()
+    assert np.median(dq_g / np.maximum(dq_o, 1e-12)) < 1.0 and np.median(dqd_g / np.maximum(dqd_o, 1e-12)) < 1.0
+    assert dq_g.max() <= 3.0 * dq_o.max() and dqd_g.max() <= 3.0 * dqd_o.max()
+    assert dqd_o.max() > 1e-4       # the states do amplify rounding: the comparison is not vacuous
+
+
+def test_config5_at_4096_envs_is_deterministic_and_permutation_equivariant():
+    """BASELINE config 5 at its full size: per-env mass scales and friction, 4096 envs, 40 steps from a
+    staggered landing. Two runs give the same bits; a batch with its envs PERMUTED - state, actions, mass scales and friction
+    permuted along - gives the permuted rows, bitwise (one env per wave: no env sees another, whatever slot or SIMD it runs on
+    and whatever the rank lists hand it)."""
+    n, steps = 4096, 40
+    g = torch.Generator(device=DEV).manual_seed(1)
+    ms = 0.8 + 0.4 * torch.rand(n, 26, device=DEV, generator=g)
+    mu = 0.5 + 0.75 * torch.rand(n, device=DEV, generator=g)
+    perm = torch.randperm(n, device=DEV, generator=g)
+    lo = torch.as_tensor(make_vec(1).action_space.low, device=DEV)
+    hi = torch.as_tensor(make_vec(1).action_space.high, device=DEV)
+    acts = lo + (hi - lo) * torch.rand(steps, n, 25, device=DEV, generator=g)
+
+    def run(order):
+        v = make_vec(n, max_episode_steps=30)
+        v.set_domain(ms[order], mu[order])
+        v.reset_tensor()
+        v.set_episode_steps((order % 30).to(torch.int32))       # episodes end inside the launches, at env-specific steps
+        out = []
+        for t in range(steps):
+            v.step_tensor(acts[t][order])
+            out.append(v.rows.clone())
+        return torch.stack(out), v.get_state()
+
+    ident = torch.arange(n, device=DEV)
+    rows_a, st_a = run(ident)
+    rows_b, st_b = run(ident)
+    assert torch.equal(rows_a, rows_b) and torch.equal(st_a, st_b)                      # determinism
+    rows_p, st_p = run(perm)
+    assert torch.equal(rows_p, rows_a[:, perm]) and torch.equal(st_p, st_a[perm])       # equivariance
+    assert torch.isfinite(rows_a).all()
+    cnt = (rows_a[-1][:, 50:75].abs() > 0).any(1).sum().item()
+    assert cnt > n // 2          # motors are on and most envs have landed: the run exercises contact rows
+    assert rows_a[:, :, 76].sum().item() >= n                                             # every env's episode ended at least once
+
+
+def test_config5_randomised_states_against_the_oracle(oracle64, oracle32, model):
+    """32 states spread over free fall, landing and rest, each with its own body-mass scales U(0.8, 1.2) and friction
+    U(0.5, 1.25) (the ranges of BASELINE config 5): one env-step on the GPU against the f64 oracle with the same domain."""
+    rng = np.random.default_rng(7)
+    q0 = model["q_start"][model["obs_order"]]
+    lo, hi = model["q_lower"][model["obs_order"]], model["q_upper"][model["obs_order"]]
+    n = 32
+    ms = rng.uniform(0.8, 1.2, (n, 26)).astype(np.float32)
+    mu = rng.uniform(0.5, 1.25, n).astype(np.float32)
+    states, acts, kinds = [], [], []
+    for e in range(n):
+        # the env's OWN trajectory under its own domain, stopped in free fall (steps 3..20), around touchdown (26..60) or at rest (150..300)
+        kind = ("airborne", "landing", "rest")[e % 3]
+        stop = {"airborne": rng.integers(3, 21), "landing": rng.integers(26, 61), "rest": rng.integers(150, 301)}[kind]
+        s = oracle64.new_state()
+        oracle64.set_domain(s, ms[e].astype(np.float64), float(mu[e]))
+        oracle64.reset(s)
+        for t in range(int(stop)):
+            oracle64.step(s, np.clip(q0 + 0.2 * rng.normal(size=25), lo, hi))
+        states.append(oracle64.get_state(s).astype(np.float32))
+        acts.append(rng.uniform(lo, hi).astype(np.float32))
+        kinds.append(kind)
+    states, acts = np.array(states), np.array(acts)
+    v = make_vec(n)
+    v.reset()
+    v.set_domain(torch.tensor(ms), torch.tensor(mu))
+    v.set_state(torch.tensor(states))
+    obs, rew, _, _ = v.step(acts)
+    cnt = torch.zeros(n, dtype=torch.int32, device=DEV)
+    v.batch.contact_stats(cnt, None)
+    in_contact, fallback = 0, []
+    for e in range(n):
+        s = oracle64.new_state()
+        oracle64.set_domain(s, ms[e].astype(np.float64), float(mu[e]))
+        oracle64.set_state(s, states[e].astype(np.float64))
+        o, r, _ = oracle64.step(s, acts[e].astype(np.float64))
+        qtol = 1e-4 + 0.01 * 3e-3 * max(1.0, np.abs(o[25:50]).max())      # (the angle error integrates the rate error over the env-step)
+        try:
+            assert_step_close(obs[e], o, rew[e], r, "config-5 %s state %d" % (kinds[e], e), q_atol=qtol)
+        except AssertionError:
+            # the way out of test_config4_size_on_one_gpu, bounded the same way: a state on which f32 ITSELF is the limit (a
+            # rex at rest hit by a full-range target jump: saturated motors on 2 kg toes under kN contact forces) is judged
+            # by 3 x the spread of the oracle's own f32 build (seven evaluations, the state moved by an f32 ulp) against f64
+            prng = np.random.default_rng(e)
+            spread = np.zeros(50)
+            for k in range(7):
+                s32 = oracle32.new_state()
+                oracle32.set_domain(s32, ms[e].astype(np.float64), float(mu[e]))
+                oracle32.set_state(s32, states[e].astype(np.float64) * (1.0 + (6e-8 * prng.standard_normal(states[e].shape) if k else 0.0)))
+                o32, _, _ = oracle32.step(s32, acts[e].astype(np.float64))
+                spread = np.maximum(spread, np.abs(o32[:50] - o[:50]))
+            assert spread[25:].max() > 1e-3 * max(1.0, np.abs(o[25:50]).max()), "well-conditioned state out of tolerance: %s %d" % (kinds[e], e)
+            assert (np.abs(obs[e][:50] - o[:50]) <= 3 * spread + 1e-6).all(), "config-5 state %d beyond 3x the f32 spread" % e
+            fallback.append(e)
+        nco = len(oracle64.contacts(s)[0])
+        assert cnt[e].item() == nco, (e, kinds[e])
+        in_contact += nco > 0
+    print("config-5 sample: %d of %d states judged by the f32-spread yardstick %s" % (len(fallback), n, fallback))
+    assert len(fallback) <= 3
+    assert 12 <= in_contact <= 28           # all three regimes are present

@@ -78,3 +78,60 @@ def test_two_ranks_on_the_gpu_gather_what_one_process_computes():
     for i in range(1, 6):                         # copy exchange: call i returns the rows of its previous step
         assert torch.equal(gc[i], rows[STEPS + i - 1]), i
     assert float(rows[3][:, 76].sum()) == N_GLOBAL     # the episode limit fired inside the launches, on every env
+
+
+NCCL_CHILD = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %(pkg)r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%(port)r)
+from trex_gym import sharding
+from trex_gym.vec_env import TrexVecEnv
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)          # "nccl" IS RCCL on ROCm
+assert dist.get_backend() == "nccl"
+for join in ("host", "stream"):
+    env = TrexVecEnv(64, urdf_path=%(urdf)r, device=dev, max_episode_steps=5, row_buffers=2)
+    env.reset_tensor()
+    ids = torch.arange(64, device=dev)
+    pipe = sharding.PipelinedGather(env.num_envs, env.rows.shape[1], 1, env.rows.dtype, dev)
+    prev_rows = None
+    for t in range(12):
+        env.step_tensor(sharding.synthetic_actions(ids, t, env.model.lower, env.model.upper, seed=0, device=dev))
+        got = pipe.push(env.rows, copy=False, wait=False, join=join)          # bench.py's call, through ProcessGroupNCCL
+        if t == 0:
+            assert got is None
+        else:
+            torch.cuda.synchronize()
+            assert torch.equal(got, prev_rows), (join, t)                     # the rows of the PREVIOUS step, bitwise
+        prev_rows = env.rows.clone()
+        w = pipe.last_work()
+        assert w is None or w.is_completed() in (True, False)                 # the completion query answers on a real NCCL work
+    last = pipe.flush()
+    torch.cuda.synchronize()
+    assert torch.equal(last, prev_rows), join
+    assert float(prev_rows[:, 76].sum()) >= 0.0
+# the blocking form and the staged form, too
+env = TrexVecEnv(32, urdf_path=%(urdf)r, device=dev)
+env.reset_tensor()
+out = sharding.all_gather_rows(env.rows, 32, 1)
+assert out is env.rows
+dist.barrier()
+dist.destroy_process_group()
+print("NCCL_WORLD_OF_ONE_OK")
+"""
+
+
+def test_pipelined_gather_over_rccl_with_a_world_of_one():
+    """the first test that touches ProcessGroupNCCL (= RCCL). One rank, one GPU: the in-place pipelined
+    gather exactly as bench.py --gpus N runs it (copy=False, wait=False), with the host join and with the stream join,
+    returns the previous step's rows bitwise, and the host join's completion query terminates on a real NCCL work handle.
+    (More than one rank per device RCCL refuses; the two-rank test above runs over gloo.)"""
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    code = NCCL_CHILD % dict(pkg=os.path.join(ROOT, "trex-gym_amd"), port=str(port), urdf=ASSET_URDF)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert "NCCL_WORLD_OF_ONE_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    assert r.returncode == 0
