@@ -111,6 +111,10 @@ int trex_batch_num_envs(const TrexBatch *batch);
 /* Forget the validated caller pointers (see the conventions above): the next call validates them afresh. */
 int trex_batch_forget_buffers(TrexBatch *batch);
 
+/* Row-block calls (trex_batch_step_rows / _reset_rows / _step_many): enabled != 0 -> columns [3J+2, 3J+5) of every row
+ * receive the three penalties; 0 (default) -> nothing beyond column 3J + 1 is written. */
+int trex_batch_set_penalties_in_rows(TrexBatch *batch, int enabled);
+
 /* Which wave runs which env. All waves of a launch of <= 4096 envs are resident at once and a SIMD is done when
  * its slowest wave is, so the step kernel can rank the envs by the contact count of their previous step and deal
  * them to the SIMDs heaviest-with-lightest (device-side state only; results are bitwise independent of it).
@@ -141,9 +145,12 @@ int trex_batch_step(TrexBatch *batch, const float *actions_dev, float *obs_dev, 
 
 /* The same two calls writing ONE row block (what the multi-GPU exchange gathers):
  *   rows_dev [N, row_stride] f32 device, row_stride >= 3J + 2:
- *     [0, 3J) observation, [3J] reward, [3J+1] done as 0.0 / 1.0; and, when row_stride >= 3J + 5, [3J+2, 3J+5) the
- *     three penalties (lifting_com, station_keeping, energy: trex_env.py:193-195) - one message for a consumer
- *     that wants them. Columns beyond are not touched.
+ *     [0, 3J) observation, [3J] reward, [3J+1] done as 0.0 / 1.0. Columns beyond 3J + 2 are NOT touched, whatever the
+ *     stride (rows padded for alignment, or embedded in a wider tensor with columns of the caller's own) - unless the
+ *     batch was told to carry the three penalties (lifting_com, station_keeping, energy: trex_env.py:193-195) in the
+ *     rows: after trex_batch_set_penalties_in_rows(batch, 1) the row calls need row_stride >= 3J + 5 and write
+ *     [3J+2, 3J+5) too (zeros from a reset) - one message for a consumer that wants them. (Until round 3 a stride of
+ *     3J + 5 or more switched this on implicitly.)
  * done_dev [N] u8, nullable: the done flags once more as bytes (what a consumer masks with - saves it a
  *   conversion pass over the column). trex_batch_reset_rows writes the observation columns of every env (reset or
  *   not) and, for the envs it resets, reward = 0 and done = 0: the row of a new episode. */

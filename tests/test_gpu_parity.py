@@ -463,6 +463,51 @@ def test_row_block_of_77_and_of_80_columns():
     assert float(wide.rows[3, 75:80].abs().sum()) == 0.0 and float(wide.rows[4, 77:80].abs().sum()) > 0.0
 
 
+def test_padded_rows_keep_the_callers_columns():
+    """rows padded for alignment or embedded in a wider tensor (row_stride 96) have columns of the caller's own
+    beyond 3J + 2 = 77. Without trex_batch_set_penalties_in_rows NOTHING beyond column 76 is written - by a step, a reset, a
+    masked reset or step_many; with it, exactly the three penalty columns 77..79 are."""
+    n, S = 40, 3
+    g = torch.Generator(device=DEV).manual_seed(5)
+    a = (torch.rand(n, 25, device=DEV, generator=g) - 0.5).contiguous()
+    many = (torch.rand(S, n, 25, device=DEV, generator=g) - 0.5).contiguous()
+    v = make_vec(n)
+    ref = make_vec(n)
+    rows = torch.full((n, 96), -7.0, device=DEV)
+    rows_many = torch.full((S, n, 96), -7.0, device=DEV)
+    v.batch.reset_rows(rows); ref.reset_tensor()
+    assert torch.equal(rows[:, :77], ref.rows) and bool((rows[:, 77:] == -7.0).all())
+    for _ in range(30):
+        v.batch.step_rows(a, rows, None); ref.step_tensor(a)
+    assert torch.equal(rows[:, :77], ref.rows) and bool((rows[:, 77:] == -7.0).all())
+    mask = torch.zeros(n, dtype=torch.uint8, device=DEV); mask[::3] = 1
+    v.batch.reset_rows(rows, mask)
+    assert bool((rows[:, 77:] == -7.0).all())
+    v.batch.step_many(many, rows_many)
+    assert bool((rows_many[:, :, 77:] == -7.0).all()) and bool(torch.isfinite(rows_many[:, :, :77]).all())
+    v.batch.set_penalties_in_rows(True)
+    pen = torch.zeros(n, 3, device=DEV)
+    v.batch.step_rows(a, rows, pen)
+    assert torch.equal(rows[:, 77:80], pen) and float(pen.abs().sum()) > 0 and bool((rows[:, 80:] == -7.0).all())
+    with pytest.raises(Exception):
+        v.batch.step_rows(a, torch.zeros(n, 78, device=DEV), None)        # the wide form needs row_stride >= 3J + 5
+
+
+def test_step_many_hands_out_the_penalties_of_every_step():
+    """step_many_tensor used to leave `penalties` at the values from before the call."""
+    n, S = 16, 4
+    g = torch.Generator(device=DEV).manual_seed(6)
+    acts = (torch.rand(S, n, 25, device=DEV, generator=g) - 0.5).contiguous()
+    one, many = make_vec(n), make_vec(n)
+    one.reset_tensor(); many.reset_tensor()
+    want = []
+    for s_ in range(S):
+        one.step_tensor(acts[s_])
+        want.append(one.penalties.clone())
+    many.step_many_tensor(acts)
+    assert torch.equal(many.penalties_many, torch.stack(want)) and torch.equal(many.penalties, want[-1])
+
+
 def test_wave_balance_setting_is_a_batch_property():
     """trex_batch_set_wave_balance: -1 auto (on from 2048 envs), 0 off, 1 on. Results are bitwise independent of it -
     also when it is forced on below the automatic threshold and when it is switched while the batch is running."""
@@ -520,10 +565,12 @@ def test_step_many_is_bitwise_the_same_steps_one_by_one(model):
         a.step_tensor(acts[s_])
         rows_a.append(a.rows.clone()); pen_a.append(a.penalties.clone()); done_a.append(a.done.clone())
     b = prepare()
+    b.batch.set_penalties_in_rows(True)                 # (explicit since round 4: a wide stride alone writes nothing beyond column 76)
     rows_b = torch.empty(S, n, 80, device=DEV)          # obs | reward | done | 3 penalties (the wide form of the row block)
     pen_b = torch.empty(S, n, 3, device=DEV)
     done_b = torch.zeros(S, n, dtype=torch.bool, device=DEV)
     b.batch.step_many(acts, rows_b, pen_b, done_b)
+    b.batch.set_penalties_in_rows(False)                # (b's own row blocks have 77 columns)
     assert bool(done_b[0, 17]) and float(rows_b[0, 17, 75]) == 0.0       # containment inside the launch
     assert int(done_b.sum()) > S * n // 9 - n                              # episodes ended in every step
     for s_ in range(S):

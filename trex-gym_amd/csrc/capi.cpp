@@ -18,9 +18,9 @@ extern "C" {
 hipError_t trex_launch_step(const TrexDeviceModel *, TrexBatchArrays, int, const float *, float *, float *, uint8_t *,
                             float *, float, float, float, float *, hipStream_t, float *, int, int, int, int);
 hipError_t trex_launch_reset(const TrexDeviceModel *, TrexBatchArrays, int, const uint8_t *, float *, float, float,
-                             float, float *, hipStream_t, int, float *, float *, int, int);
+                             float, float *, hipStream_t, int, float *, float *, int, int, int);
 hipError_t trex_launch_step_many(const TrexDeviceModel *, TrexBatchArrays, int, const float *, float *, int, int, float *, uint8_t *,
-                                 float, float, float, hipStream_t, int, int);
+                                 float, float, float, hipStream_t, int, int, int);
 hipError_t trex_launch_pack_state(const TrexDeviceModel *, TrexBatchArrays, int, float *, int, hipStream_t);
 hipError_t trex_launch_head(const TrexDeviceModel *, TrexBatchArrays, int, float *, hipStream_t);
 hipError_t trex_launch_link_transforms(const TrexDeviceModel *, TrexBatchArrays, int, float *, hipStream_t, int);
@@ -42,6 +42,7 @@ struct TrexBatch {
   TrexDeviceModel *dmodel = nullptr;
   TrexBatchArrays arr{};
   float wd = 1.0f, we = 0.005f, wk = 0.002f;  // trex_env.py:42-44
+  bool pen_in_rows = false;                    // trex_batch_set_penalties_in_rows
   int balance_mode = -1;                       // trex_batch_set_wave_balance: -1 auto, 0 off, 1 on
   bool balance() const { return balance_mode < 0 ? n >= 2048 : balance_mode != 0; }
   std::vector<void *> allocs;
@@ -484,6 +485,12 @@ int trex_batch_set_wave_balance(TrexBatch *b, int mode) {
   return TREX_OK;
 }
 
+int trex_batch_set_penalties_in_rows(TrexBatch *b, int enabled) {
+  if (check_batch(b)) return TREX_E_INVALID;
+  b->pen_in_rows = enabled != 0;
+  return TREX_OK;
+}
+
 int trex_batch_forget_buffers(TrexBatch *b) {
   if (check_batch(b)) return TREX_E_INVALID;
   b->seen.clear();
@@ -497,20 +504,21 @@ int trex_batch_reset(TrexBatch *b, const uint8_t *mask_dev, float *obs_out_dev, 
   BUF_TRY(mask_dev, n, "trex_batch_reset: mask");
   BUF_TRY(obs_out_dev, n * 3 * b->nj * sizeof(float), "trex_batch_reset: obs_out");
   HIP_TRY(trex_launch_reset(b->dmodel, b->arr, b->n, mask_dev, obs_out_dev, b->wd, b->we, b->wk, nullptr,
-                            (hipStream_t)stream, 3 * b->nj, nullptr, nullptr, 1, b->nj));
+                            (hipStream_t)stream, 3 * b->nj, nullptr, nullptr, 1, b->nj, 0));
   return TREX_OK;
 }
 
 int trex_batch_reset_rows(TrexBatch *b, const uint8_t *mask_dev, float *rows_dev, int row_stride, void *stream) {
   if (check_batch(b)) return TREX_E_INVALID;
   if (!rows_dev) return fail(TREX_E_INVALID, "trex_batch_reset_rows: rows is null");
-  if (row_stride < 3 * b->nj + 2) return fail(TREX_E_INVALID, "trex_batch_reset_rows: row_stride < 3J + 2");
+  if (row_stride < 3 * b->nj + (b->pen_in_rows ? 5 : 2)) return fail(TREX_E_INVALID, "trex_batch_reset_rows: row_stride < 3J + 2 (3J + 5 with penalties in rows)");
   DeviceGuard guard(b->device);
   const size_t n = (size_t)b->n;
   BUF_TRY(mask_dev, n, "trex_batch_reset_rows: mask");
-  BUF_TRY(rows_dev, ((n - 1) * row_stride + 3 * b->nj + (row_stride >= 3 * b->nj + 5 ? 5 : 2)) * sizeof(float), "trex_batch_reset_rows: rows");
+  BUF_TRY(rows_dev, ((n - 1) * row_stride + 3 * b->nj + (b->pen_in_rows ? 5 : 2)) * sizeof(float), "trex_batch_reset_rows: rows");
   HIP_TRY(trex_launch_reset(b->dmodel, b->arr, b->n, mask_dev, rows_dev, b->wd, b->we, b->wk, nullptr,
-                            (hipStream_t)stream, row_stride, rows_dev + 3 * b->nj, rows_dev + 3 * b->nj + 1, row_stride, b->nj));
+                            (hipStream_t)stream, row_stride, rows_dev + 3 * b->nj, rows_dev + 3 * b->nj + 1, row_stride, b->nj,
+                            b->pen_in_rows ? 1 : 0));
   return TREX_OK;
 }
 
@@ -534,16 +542,16 @@ int trex_batch_step_rows(TrexBatch *b, const float *actions_dev, float *rows_dev
                          uint8_t *done_dev, void *stream) {
   if (check_batch(b)) return TREX_E_INVALID;
   if (!actions_dev || !rows_dev) return fail(TREX_E_INVALID, "trex_batch_step_rows: null argument");
-  if (row_stride < 3 * b->nj + 2) return fail(TREX_E_INVALID, "trex_batch_step_rows: row_stride < 3J + 2");
+  if (row_stride < 3 * b->nj + (b->pen_in_rows ? 5 : 2)) return fail(TREX_E_INVALID, "trex_batch_step_rows: row_stride < 3J + 2 (3J + 5 with penalties in rows)");
   DeviceGuard guard(b->device);
   const size_t n = (size_t)b->n;
   BUF_TRY(actions_dev, n * b->nj * sizeof(float), "trex_batch_step_rows: actions");
-  BUF_TRY(rows_dev, ((n - 1) * row_stride + 3 * b->nj + (row_stride >= 3 * b->nj + 5 ? 5 : 2)) * sizeof(float), "trex_batch_step_rows: rows");
+  BUF_TRY(rows_dev, ((n - 1) * row_stride + 3 * b->nj + (b->pen_in_rows ? 5 : 2)) * sizeof(float), "trex_batch_step_rows: rows");
   BUF_TRY(penalties_dev, n * 3 * sizeof(float), "trex_batch_step_rows: penalties");
   BUF_TRY(done_dev, n, "trex_batch_step_rows: done");
   float *rew = rows_dev + 3 * b->nj;
   HIP_TRY(trex_launch_step(b->dmodel, b->arr, b->n, actions_dev, rows_dev, rew, done_dev, penalties_dev, b->wd, b->we,
-                           b->wk, nullptr, (hipStream_t)stream, rew + 1, row_stride, row_stride, b->balance(), row_stride >= 3 * b->nj + 5));
+                           b->wk, nullptr, (hipStream_t)stream, rew + 1, row_stride, row_stride, b->balance(), b->pen_in_rows ? 1 : 0));
   return TREX_OK;
 }
 
@@ -552,15 +560,15 @@ int trex_batch_step_many(TrexBatch *b, const float *actions_dev, float *rows_dev
   if (check_batch(b)) return TREX_E_INVALID;
   if (!actions_dev || !rows_dev) return fail(TREX_E_INVALID, "trex_batch_step_many: null argument");
   if (num_steps < 1) return fail(TREX_E_INVALID, "trex_batch_step_many: num_steps must be >= 1");
-  if (row_stride < 3 * b->nj + 2) return fail(TREX_E_INVALID, "trex_batch_step_many: row_stride < 3J + 2");
+  if (row_stride < 3 * b->nj + (b->pen_in_rows ? 5 : 2)) return fail(TREX_E_INVALID, "trex_batch_step_many: row_stride < 3J + 2 (3J + 5 with penalties in rows)");
   DeviceGuard guard(b->device);
   const size_t n = (size_t)b->n, S = (size_t)num_steps;
   BUF_TRY(actions_dev, S * n * b->nj * sizeof(float), "trex_batch_step_many: actions");
-  BUF_TRY(rows_dev, ((S * n - 1) * row_stride + 3 * b->nj + (row_stride >= 3 * b->nj + 5 ? 5 : 2)) * sizeof(float), "trex_batch_step_many: rows");
+  BUF_TRY(rows_dev, ((S * n - 1) * row_stride + 3 * b->nj + (b->pen_in_rows ? 5 : 2)) * sizeof(float), "trex_batch_step_many: rows");
   BUF_TRY(penalties_dev, S * n * 3 * sizeof(float), "trex_batch_step_many: penalties");
   BUF_TRY(done_dev, S * n, "trex_batch_step_many: done");
   HIP_TRY(trex_launch_step_many(b->dmodel, b->arr, b->n, actions_dev, rows_dev, row_stride, num_steps, penalties_dev, done_dev,
-                                b->wd, b->we, b->wk, (hipStream_t)stream, b->balance(), b->nj));
+                                b->wd, b->we, b->wk, (hipStream_t)stream, b->balance(), b->nj, b->pen_in_rows ? 1 : 0));
   return TREX_OK;
 }
 

@@ -363,7 +363,7 @@ struct KernelArgs {
   // row block at + s * step_rows floats (obs, reward, done_f alike), done bytes at + s * N, penalties at + s * 3 N
   int n_steps;
   long long step_rows;
-  int pen_in_rows;        // row-block launches with row_stride >= 3J + 5: the three penalties follow done in the row
+  int pen_in_rows;        // row-block launches of a batch with trex_batch_set_penalties_in_rows: the three penalties follow done in the row
 };
 
 }  // namespace
@@ -2299,19 +2299,19 @@ hipError_t trex_launch_step(const TrexDeviceModel *model, TrexBatchArrays arr, i
 // penalties [S, N, 3] and done bytes [S, N] nullable
 hipError_t trex_launch_step_many(const TrexDeviceModel *model, TrexBatchArrays arr, int n, const float *actions, float *rows,
                                  int row_stride, int n_steps, float *penalties, uint8_t *done, float wd, float we, float wk,
-                                 hipStream_t stream, int balance, int nj) {
+                                 hipStream_t stream, int balance, int nj, int pen_in_rows) {
   float *rew = rows + 3 * nj;
   KernelArgs a{model, arr, n, actions, rows, rew, done, rew + 1, row_stride, row_stride, penalties, nullptr,
-               balance ? arr.balance : nullptr, wd, we, wk, nullptr, n_steps, (long long)n * row_stride, row_stride >= 3 * nj + 5};
+               balance ? arr.balance : nullptr, wd, we, wk, nullptr, n_steps, (long long)n * row_stride, pen_in_rows};
   hipLaunchKernelGGL(trex_step_many_kernel, dim3(n), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
 
 hipError_t trex_launch_reset(const TrexDeviceModel *model, TrexBatchArrays arr, int n, const uint8_t *mask,
                              float *obs, float wd, float we, float wk, float *debug, hipStream_t stream, int obs_stride,
-                             float *reward, float *done_f, int scal_stride, int nj) {
+                             float *reward, float *done_f, int scal_stride, int nj, int pen_in_rows) {
   KernelArgs a{model, arr, n, nullptr, obs, reward, nullptr, done_f, obs_stride, scal_stride, nullptr, mask, nullptr, wd, we, wk, debug,
-               1, 0, (reward && done_f && obs_stride >= 3 * nj + 5) ? 1 : 0};
+               1, 0, (reward && done_f && pen_in_rows) ? 1 : 0};
   hipLaunchKernelGGL((trex_step_kernel<true, false>), dim3(n), dim3(64), 0, stream, a);
   return hipGetLastError();
 }

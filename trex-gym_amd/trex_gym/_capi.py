@@ -38,7 +38,7 @@ SYMBOLS = [
     "trex_model_use_primitive_collision", "trex_model_fit_hull_primitives",
     "trex_build_id", "trex_batch_step_rows", "trex_batch_reset_rows",
     "trex_batch_set_episode_limit", "trex_batch_get_episode_steps",
-    "trex_batch_set_wave_balance", "trex_batch_forget_buffers",
+    "trex_batch_set_wave_balance", "trex_batch_forget_buffers", "trex_batch_set_penalties_in_rows",
     "trex_model_num_visuals", "trex_model_visual_info", "trex_batch_visual_transforms", "trex_batch_step_many",
 ]
 
@@ -82,6 +82,7 @@ lib.trex_batch_set_episode_limit.argtypes = [_vp, C.c_int, _vp, _vp]
 lib.trex_batch_get_episode_steps.argtypes = [_vp, _vp, _vp]
 lib.trex_batch_set_wave_balance.argtypes = [_vp, C.c_int]
 lib.trex_batch_forget_buffers.argtypes = [_vp]
+lib.trex_batch_set_penalties_in_rows.argtypes = [_vp, C.c_int]
 lib.trex_batch_debug_step.argtypes = [_vp, _vp, _vp, _vp, _vp]
 lib.trex_batch_get_state.argtypes = [_vp, _vp, _vp]
 lib.trex_batch_set_state.argtypes = [_vp, _vp, _vp]
@@ -303,6 +304,13 @@ class Batch:
     def forget_buffers(self):
         check(lib.trex_batch_forget_buffers(self.h))
 
+    pen_in_rows = False
+
+    def set_penalties_in_rows(self, enabled):
+        self.pen_in_rows = bool(enabled)
+        """Row-block calls write the three penalties to columns 3J+2 .. 3J+4 (row_stride >= 3J + 5): include/trex_batch.h."""
+        check(lib.trex_batch_set_penalties_in_rows(self.h, 1 if enabled else 0))
+
     def reset(self, obs_out=None, mask=None, stream=None):
         n, J = self.num_envs, self.J
         check(lib.trex_batch_reset(self.h, self._mask(mask), self._p(obs_out, "float32", n * 3 * J, "obs_out"),
@@ -322,7 +330,7 @@ class Batch:
         if done is not None and done.dtype not in (torch.uint8, torch.bool):
             raise TrexError(E_INVALID, "done: expected dtype uint8 or bool, got %s" % done.dtype)
         check(lib.trex_batch_step_rows(self.h, self._p(actions, "float32", n * J, "actions"),
-                                       self._p(rows, "float32", (n - 1) * rows.shape[1] + 3 * J + (5 if rows.shape[1] >= 3 * J + 5 else 2), "rows"), int(rows.shape[1]),
+                                       self._p(rows, "float32", (n - 1) * rows.shape[1] + 3 * J + (5 if self.pen_in_rows else 2), "rows"), int(rows.shape[1]),
                                        self._p(penalties, "float32", 3 * n, "penalties"),
                                        _ptr(done, self.device, None, n, "done"), self._stream(stream)))
 
@@ -335,14 +343,14 @@ class Batch:
         if rows.dim() != 3 or int(rows.shape[0]) != S or int(rows.shape[1]) != n:
             raise TrexError(E_INVALID, "rows: expected shape [%d, %d, >= %d], got %s" % (S, n, 3 * J + 2, tuple(rows.shape)))
         check(lib.trex_batch_step_many(self.h, self._p(actions, "float32", S * n * J, "actions"),
-                                       self._p(rows, "float32", (S * n - 1) * rows.shape[2] + 3 * J + (5 if rows.shape[2] >= 3 * J + 5 else 2), "rows"), int(rows.shape[2]), S,
+                                       self._p(rows, "float32", (S * n - 1) * rows.shape[2] + 3 * J + (5 if self.pen_in_rows else 2), "rows"), int(rows.shape[2]), S,
                                        self._p(penalties, "float32", 3 * S * n, "penalties"), _ptr(done, self.device, None, S * n, "done"),
                                        self._stream(stream)))
 
     def reset_rows(self, rows, mask=None, stream=None):
         n, J = self.num_envs, self.J
         check(lib.trex_batch_reset_rows(self.h, self._mask(mask),
-                                        self._p(rows, "float32", (n - 1) * rows.shape[1] + 3 * J + (5 if rows.shape[1] >= 3 * J + 5 else 2), "rows"),
+                                        self._p(rows, "float32", (n - 1) * rows.shape[1] + 3 * J + (5 if self.pen_in_rows else 2), "rows"),
                                         int(rows.shape[1]), self._stream(stream)))
 
     def set_episode_limit(self, max_episode_steps, episode_steps=None, stream=None):

@@ -53,21 +53,31 @@ def train(env, num_timesteps, seed, nsteps=32, noptepochs=None, save_path=None, 
     return agent, hist
 
 
-def play(agent, num_play_timesteps, export_path=None, env_index=0, log=print):
+def play(agent, num_play_timesteps, export_path=None, env_index=0, log=print, deterministic=False, update_stats=True, seed=0):
     """The reference's play loop (trex_train.py:126-136: model.step -> env.step -> render a frame -> PNGs -> ffmpeg) up to
-    the renderer: the trained policy drives the env with the MEAN action and every frame's world poses of the 252 visual
-    meshes are recorded (trex_batch_visual_transforms) - what a renderer needs to draw the frame; drawing itself is out
-    of scope. export_path: .npz with `mesh_files`, `mesh_links`, `poses` [T, 252, 7] (xyz + quaternion xyzw
-    of env `env_index`), `reward` [T], `fps` = 50 (metadata of trex_env.py:36)."""
+    the renderer: every frame's world poses of the 252 visual meshes are recorded (trex_batch_visual_transforms) - what a
+    renderer needs to draw the frame; drawing itself is out of scope.
+    Defaults = the reference's behaviour: `model.step(obs)[0]` is a SAMPLED action (deterministic=False: N(0, 1) noise for
+    the policy kernel) and the VecNormalize env it plays in keeps updating its running statistics with every observation
+    (update_stats=True: the statistics kernel runs after each step). deterministic=True plays the mean action,
+    update_stats=False freezes the statistics after the reset - the repeatable variant for comparing checkpoints (what this
+    function did until round 3, then under the name of the reference's loop).
+    export_path: .npz with `mesh_files`, `mesh_links`, `poses` [T, 252, 7] (xyz + quaternion xyzw of env `env_index`),
+    `reward` [T], `fps` = 50 (metadata of trex_env.py:36)."""
     import numpy as np
     env, k = agent.env, agent.kern
-    zero = torch.zeros(env.num_envs, env.J, device=env.device)
+    noise = torch.zeros(env.num_envs, env.J, device=env.device)
+    gen = torch.Generator(device=env.device).manual_seed(int(seed))
     frames, rewards = [], []
     env.reset_tensor()
     k.observe(env.rows, with_reward=False)
     for _ in range(num_play_timesteps):
-        k.act(agent.policy.theta, env.rows, zero, agent.actions, clip_obs=agent.clip_obs)     # zero noise: the mean action
+        if not deterministic:
+            noise.normal_(generator=gen)
+        k.act(agent.policy.theta, env.rows, noise, agent.actions, clip_obs=agent.clip_obs)
         env.step_tensor(agent.actions)
+        if update_stats:
+            k.observe(env.rows)       # (VecNormalize.step_wait: the observation moments AND the return moments move on)
         frames.append(env.visual_transforms()[env_index].cpu().numpy())
         rewards.append(float(env.rew[env_index]))
     log("Episode reward: %.3f over %d frames" % (sum(rewards), len(rewards)))
@@ -109,12 +119,13 @@ def main(argv=None):
     ap.add_argument("--play", action="store_true", help="after training: run the policy and record the frames' mesh poses (trex_train.py:25,126-136)")
     ap.add_argument("--num_play_timesteps", type=int, default=int(2e3))          # trex_train.py:28
     ap.add_argument("--export", type=str, default=None, help="with --play: .npz of mesh names + [T, 252, 7] world poses for an external renderer")
+    ap.add_argument("--play_deterministic", action="store_true", help="with --play: the mean action and frozen normalisation statistics (the reference samples and keeps updating)")
     args = ap.parse_args(argv)
     env = build_environment(args.num_envs, max_episode_steps=args.max_episode_steps)
     agent, _ = train(env, args.num_timesteps, args.random_seed, args.nsteps, args.noptepochs, args.save, use_graphs=args.graphs,
                      preset=args.preset)
     if args.play:
-        play(agent, args.num_play_timesteps, args.export)
+        play(agent, args.num_play_timesteps, args.export, deterministic=args.play_deterministic, update_stats=not args.play_deterministic)
 
 
 if __name__ == "__main__":

@@ -74,6 +74,7 @@ class TrexVecEnv(spaces.Env):       # gym.Env where gym is importable; the surfa
         # wants them); default [n, 3J+2] + a `penalties` tensor of its own. (The 80-column form was MEASURED to cost
         # more HBM write traffic, not less - 8.1 against 3.7 MB per launch of 4096 envs, PMC WRITE_SIZE: DESIGN.md 6.)
         self._pen_in_rows = bool(penalties_in_rows)
+        self.batch.set_penalties_in_rows(self._pen_in_rows)      # (explicit: a wide row stride alone writes nothing beyond column 3J + 1)
         self._row_blocks = [torch.zeros(n, 3 * J + (5 if self._pen_in_rows else 2), device=self.device) for _ in range(int(row_buffers))]
         self._penalties = None if self._pen_in_rows else torch.zeros(n, 3, device=self.device)
         self._row_k = 0
@@ -136,8 +137,13 @@ class TrexVecEnv(spaces.Env):       # gym.Env where gym is importable; the surfa
         S = int(actions.shape[0])
         if rows is None:
             rows = torch.empty(S, self.num_envs, self.rows.shape[1], device=self.device)
-        self.batch.step_many(actions, rows)
+        # (the three reward terms of every step: in the rows when penalties_in_rows, else in `penalties_many` [S, n, 3]; `penalties`
+        # then holds the last step's, like the other views - it used to keep the values from BEFORE the call)
+        self.penalties_many = None if self._pen_in_rows else torch.empty(S, self.num_envs, 3, device=self.device)
+        self.batch.step_many(actions, rows, self.penalties_many)
         self.rows.copy_(rows[-1])
+        if not self._pen_in_rows:
+            self._penalties.copy_(self.penalties_many[-1])
         self.done.copy_(self.done_f != 0)
         return rows
 
@@ -223,6 +229,8 @@ class TrexVecEnv(spaces.Env):       # gym.Env where gym is importable; the surfa
         return self.step_wait()
 
     def close(self):
+        # the batch caches the device allocations it has validated; the buffers of this env go back to torch's allocator now
+        self.batch.forget_buffers()
         self.batch.close()
 
     def render(self, mode="rgb_array"):
