@@ -101,6 +101,18 @@ int trex_policy_adam_reset(TrexPolicy *policy, void *stream);
  *   obs_dim <= 96 here (TREX_E_INVALID beyond: the kernel stages 96 observation columns per sample). */
 int trex_policy_minibatch_stats(TrexPolicy *policy, const float *adv_dev, int64_t num_samples, const int64_t *perm_dev,
                                 int num_minibatches, int mb, float *stats_out_dev, void *stream);
+/* trex_policy_minibatch_grad: the first two launches of trex_policy_minibatch_step alone - the minibatch's gradient
+ *   (entropy term included, UNclipped) times grad_scale -> grad_dev [P]; no clip, no Adam, the step count does not move.
+ *   For a DATA-PARALLEL trainer (one process per GPU, each with its own envs and rollout; SURVEY 8e: "only PPO gradient
+ *   all-reduce remains"): every rank calls this with grad_scale = 1 / ranks on its share of the minibatch, the ranks SUM
+ *   grad_dev (torch.distributed.all_reduce over RCCL), then every rank applies trex_policy_adam - the update of the
+ *   concatenated minibatch, on every rank the same. adv_stats must then be the statistics of the WHOLE minibatch (all
+ *   ranks' shares; trex_gym/ppo.py forms them). loss_sums_dev as above, scaled by grad_scale too. */
+int trex_policy_minibatch_grad(TrexPolicy *policy, const float *theta_dev, float *grad_dev, const float *obs_dev,
+                               const float *act_dev, const float *logp_dev, const float *val_dev, const float *adv_dev,
+                               const float *ret_dev, int64_t num_samples, const int64_t *perm_dev, int first, int mb,
+                               const float *adv_stats_dev, float cliprange, float ent_coef, float vf_coef, float grad_scale,
+                               float *loss_sums_dev, void *stream);
 int trex_policy_minibatch_step(TrexPolicy *policy, float *theta_dev, float *grad_dev, float *m_dev, float *v_dev,
                                const float *obs_dev, const float *act_dev, const float *logp_dev, const float *val_dev,
                                const float *adv_dev, const float *ret_dev, int64_t num_samples, const int64_t *perm_dev,

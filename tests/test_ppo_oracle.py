@@ -1,6 +1,8 @@
 """The trainer-side oracle (oracle/ppo_oracle.py: f64 numpy restatement of GAE, the PPO2 losses, Adam and
 VecNormalize's running statistics - parity unpinned: baselines / TensorFlow are absent, see its header) checked
 against itself: analytic gradients vs central differences, closed forms, and plain numpy on the pooled data."""
+import os
+
 import numpy as np
 import pytest
 
@@ -96,3 +98,39 @@ def test_adam_first_steps_and_global_norm_clip():
     # t = 1: m = 0.1 g, v = 0.001 g^2, lr_t = lr sqrt(0.001) / 0.1 -> step = lr g / (|g| + eps / sqrt(0.001))
     want = np.array([1.0, -2.0]) - 1e-2 * g["w"] / (np.abs(g["w"]) + 1e-5 / np.sqrt(1e-3))
     np.testing.assert_allclose(p["w"], want, rtol=1e-12)
+
+
+def test_running_moments_merge_across_ranks():
+    """trex_gym.ppo.merge_running_moments (the data-parallel trainer's once-per-rollout exchange): every rank starts from
+    the same statistics and folds in its own data; the merged statistics are those of the prefix data and every rank's new
+    data ONCE - checked against numpy on the concatenation, for vectors (observations) and scalars (returns)."""
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "trex-gym_amd"))
+    from trex_gym.ppo import merge_running_moments
+
+    def chan(mean, var, count, x):      # RunningMeanStd.update (baselines): fold a batch in
+        bm, bv, bn = x.mean(0), x.var(0), x.shape[0]
+        delta, tot = bm - mean, count + bn
+        return mean + delta * bn / tot, (var * count + bv * bn + delta ** 2 * count * bn / tot) / tot, tot
+
+    rng = np.random.default_rng(0)
+    D = 7
+    base = rng.normal(2.0, 3.0, (500, D))
+    prefix = chan(np.zeros(D), np.ones(D), 1e-4, base)
+    parts, new = [], []
+    for r, n in enumerate((4096, 4096, 37)):
+        x = rng.normal(-1.0 + r, 0.5 + r, (n, D))
+        new.append(x)
+        parts.append(chan(*prefix, x))
+    mean, var, cnt = merge_running_moments(prefix, parts)
+    want = chan(*prefix, np.concatenate(new))
+    np.testing.assert_allclose(mean, want[0], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(var, want[1], rtol=1e-10)
+    assert abs(cnt - want[2]) < 1e-6
+    # a rank that saw nothing new changes nothing; scalars work too
+    m2, v2, c2 = merge_running_moments(prefix, [prefix, parts[0]])
+    np.testing.assert_allclose(m2, parts[0][0], rtol=1e-12)
+    sm, sv, sc = merge_running_moments((0.5, 2.0, 10.0), [chan(0.5, 2.0, 10.0, np.array([1.0, 3.0, 5.0])), chan(0.5, 2.0, 10.0, np.array([-2.0]))])
+    w = chan(0.5, 2.0, 10.0, np.array([1.0, 3.0, 5.0, -2.0]))
+    assert abs(sm - w[0]) < 1e-12 and abs(sv - w[1]) < 1e-12 and sc == 14.0

@@ -437,6 +437,8 @@ struct ApplyArgs {
   int *step;
   int tiles, stride, count, logstd_off, A;
   float ent_coef, lr, b1, b2, eps, max_norm, inv_mb;
+  float grad_scale;      // the gradient (entropy term included) and the loss sums are multiplied by this: 1 / ranks for a data-parallel step
+  int advance;           // != 0: workgroup 0 advances the Adam step count and forms its step size (the Adam launch follows)
 };
 
 // Two launches (measured in round 4 and not kept: ONE launch with a grid barrier between the column sums and Adam - arrival
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(AP_COLS * AP_GROUPS) void learn_reduce_kernel(Apply
 #pragma unroll
     for (int q = 1; q < AP_GROUPS; q++) { t.x += part[q][c].x; t.y += part[q][c].y; t.z += part[q][c].z; t.w += part[q][c].w; }
     if (c4 == n4 - 1) {                                 // the loss sums of the minibatch (x: surrogate, y: value)
-      if (g.losses) { g.losses[0] += t.x * g.inv_mb; g.losses[1] += t.y * g.inv_mb; }
+      if (g.losses) { g.losses[0] += t.x * g.inv_mb * g.grad_scale; g.losses[1] += t.y * g.inv_mb * g.grad_scale; }
     } else {
       float e[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
@@ -481,6 +483,7 @@ __global__ __launch_bounds__(AP_COLS * AP_GROUPS) void learn_reduce_kernel(Apply
         const int i = 4 * c4 + k;
         if (i >= g.count) e[k] = 0.f;
         else if (i >= g.logstd_off && i < g.logstd_off + g.A) e[k] -= g.ent_coef;      // d(-ent_coef * entropy)/dlogstd
+        e[k] *= g.grad_scale;                                                         // (1: a multiplication by one is exact)
         sq += (double)e[k] * e[k];
       }
       if (4 * c4 + 3 < g.count) reinterpret_cast<float4 *>(g.grad)[c4] = make_float4(e[0], e[1], e[2], e[3]);
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(AP_COLS * AP_GROUPS) void learn_reduce_kernel(Apply
     double t = 0.0;
     for (int w = 0; w < AP_COLS * AP_GROUPS / 64; w++) t += wred[w];
     g.red[blockIdx.x] = t;
-    if (blockIdx.x == 0) {
+    if (blockIdx.x == 0 && g.advance) {
       // the Adam step count and TensorFlow's step size for it, formed HERE, off the Adam launch's critical path (two double
       // pow() by one thread cost that launch about a microsecond): lr_t = lr sqrt(1 - b2^t) / (1 - b1^t)
       const int st = *g.step + 1;
@@ -560,31 +563,31 @@ int trex_policy_minibatch_stats(TrexPolicy *p, const float *adv_dev, int64_t num
   return TREX_OK;
 }
 
-int trex_policy_minibatch_step(TrexPolicy *p, float *theta_dev, float *grad_dev, float *m_dev, float *v_dev, const float *obs_dev,
-                               const float *act_dev, const float *logp_dev, const float *val_dev, const float *adv_dev,
-                               const float *ret_dev, int64_t num_samples, const int64_t *perm_dev, int first, int mb,
-                               const float *adv_stats_dev, float cliprange, float ent_coef, float vf_coef, float lr, float beta1,
-                               float beta2, float eps, float max_grad_norm, float *loss_sums_dev, void *stream) {
-  if (!p || !theta_dev || !grad_dev || !m_dev || !v_dev || !obs_dev || !act_dev || !logp_dev || !val_dev || !adv_dev || !ret_dev ||
-      !perm_dev || !adv_stats_dev)
-    return trex_fail(TREX_E_INVALID, "trex_policy_minibatch_step: null argument");
-  if (mb <= 0 || first < 0 || num_samples <= 0) return trex_fail(TREX_E_INVALID, "trex_policy_minibatch_step: bad sizes");
-  if (p->D > 96) return trex_fail(TREX_E_INVALID, "trex_policy_minibatch_step: the learner stages 96 observation columns (obs_dim <= 96)");
-  TrexDeviceGuard guard(p->device);
+// gradient of one minibatch: learn_grad_kernel + learn_reduce_kernel -> grad_dev (UNclipped, times grad_scale)
+static int launch_minibatch_grad(TrexPolicy *p, const char *who, float *theta_dev, float *grad_dev, float *m_dev, float *v_dev,
+                                 const float *obs_dev, const float *act_dev, const float *logp_dev, const float *val_dev,
+                                 const float *adv_dev, const float *ret_dev, int64_t num_samples, const int64_t *perm_dev, int first,
+                                 int mb, const float *adv_stats_dev, float cliprange, float ent_coef, float vf_coef, float lr,
+                                 float beta1, float beta2, float eps, float max_grad_norm, float grad_scale, int advance,
+                                 float *loss_sums_dev, void *stream, ApplyArgs *out_args, int *out_groups) {
+  if (!p || !theta_dev || !grad_dev || !obs_dev || !act_dev || !logp_dev || !val_dev || !adv_dev || !ret_dev || !perm_dev || !adv_stats_dev)
+    return trex_fail(TREX_E_INVALID, std::string(who) + ": null argument");
+  if (mb <= 0 || first < 0 || num_samples <= 0) return trex_fail(TREX_E_INVALID, std::string(who) + ": bad sizes");
+  if (p->D > 96) return trex_fail(TREX_E_INVALID, std::string(who) + ": the learner stages 96 observation columns (obs_dim <= 96)");
   const size_t P = (size_t)p->lay.count, N = (size_t)num_samples;
-  BUF_TRY(theta_dev, P * sizeof(float), "trex_policy_minibatch_step: theta");
-  BUF_TRY(grad_dev, P * sizeof(float), "trex_policy_minibatch_step: grad");
-  BUF_TRY(m_dev, P * sizeof(float), "trex_policy_minibatch_step: m");
-  BUF_TRY(v_dev, P * sizeof(float), "trex_policy_minibatch_step: v");
-  BUF_TRY(obs_dev, N * p->D * sizeof(float), "trex_policy_minibatch_step: obs");
-  BUF_TRY(act_dev, N * p->A * sizeof(float), "trex_policy_minibatch_step: act");
-  BUF_TRY(logp_dev, N * sizeof(float), "trex_policy_minibatch_step: logp");
-  BUF_TRY(val_dev, N * sizeof(float), "trex_policy_minibatch_step: val");
-  BUF_TRY(adv_dev, N * sizeof(float), "trex_policy_minibatch_step: adv");
-  BUF_TRY(ret_dev, N * sizeof(float), "trex_policy_minibatch_step: ret");
-  BUF_TRY(perm_dev, ((size_t)first + mb) * sizeof(int64_t), "trex_policy_minibatch_step: perm");
-  BUF_TRY(adv_stats_dev, 2 * sizeof(float), "trex_policy_minibatch_step: adv_stats");
-  BUF_TRY(loss_sums_dev, 2 * sizeof(float), "trex_policy_minibatch_step: loss_sums");
+  BUF_TRY(theta_dev, P * sizeof(float), "minibatch step: theta");
+  BUF_TRY(grad_dev, P * sizeof(float), "minibatch step: grad");
+  BUF_TRY(m_dev, P * sizeof(float), "minibatch step: m");
+  BUF_TRY(v_dev, P * sizeof(float), "minibatch step: v");
+  BUF_TRY(obs_dev, N * p->D * sizeof(float), "minibatch step: obs");
+  BUF_TRY(act_dev, N * p->A * sizeof(float), "minibatch step: act");
+  BUF_TRY(logp_dev, N * sizeof(float), "minibatch step: logp");
+  BUF_TRY(val_dev, N * sizeof(float), "minibatch step: val");
+  BUF_TRY(adv_dev, N * sizeof(float), "minibatch step: adv");
+  BUF_TRY(ret_dev, N * sizeof(float), "minibatch step: ret");
+  BUF_TRY(perm_dev, ((size_t)first + mb) * sizeof(int64_t), "minibatch step: perm");
+  BUF_TRY(adv_stats_dev, 2 * sizeof(float), "minibatch step: adv_stats");
+  BUF_TRY(loss_sums_dev, 2 * sizeof(float), "minibatch step: loss_sums");
   const int tiles = (mb + TILE - 1) / TILE;
   const int stride = (int)(((P + 3) & ~(size_t)3) + 4);       // parameters, padded to float4, + one float4 of loss sums
   const int apply_groups = ((stride >> 2) + AP_COLS - 1) / AP_COLS;
@@ -608,12 +611,43 @@ int trex_policy_minibatch_step(TrexPolicy *p, float *theta_dev, float *grad_dev,
   hipLaunchKernelGGL(learn_grad_kernel, dim3(tiles, 2), dim3(256), (size_t)L.total * sizeof(float), (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
   ApplyArgs b{p->grad_partial, theta_dev, grad_dev, m_dev, v_dev, loss_sums_dev, p->learn_red, p->learn_counter, p->adam_step,
-              tiles, stride, p->lay.count, p->lay.logstd, p->A, ent_coef, lr, beta1, beta2, eps, max_grad_norm, 1.0f / (float)mb};
+              tiles, stride, p->lay.count, p->lay.logstd, p->A, ent_coef, lr, beta1, beta2, eps, max_grad_norm, 1.0f / (float)mb,
+              grad_scale, advance};
   hipLaunchKernelGGL(learn_reduce_kernel, dim3(apply_groups), dim3(AP_COLS * AP_GROUPS), 0, (hipStream_t)stream, b);
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(learn_adam_kernel, dim3(((p->lay.count >> 2) + 255) / 256), dim3(256), 0, (hipStream_t)stream, b, apply_groups);
+  if (out_args) *out_args = b;
+  if (out_groups) *out_groups = apply_groups;
+  return TREX_OK;
+}
+
+int trex_policy_minibatch_step(TrexPolicy *p, float *theta_dev, float *grad_dev, float *m_dev, float *v_dev, const float *obs_dev,
+                               const float *act_dev, const float *logp_dev, const float *val_dev, const float *adv_dev,
+                               const float *ret_dev, int64_t num_samples, const int64_t *perm_dev, int first, int mb,
+                               const float *adv_stats_dev, float cliprange, float ent_coef, float vf_coef, float lr, float beta1,
+                               float beta2, float eps, float max_grad_norm, float *loss_sums_dev, void *stream) {
+  if (!p || !m_dev || !v_dev) return trex_fail(TREX_E_INVALID, "trex_policy_minibatch_step: null argument");
+  TrexDeviceGuard guard(p->device);
+  ApplyArgs b{};
+  int groups = 0;
+  if (int rc = launch_minibatch_grad(p, "trex_policy_minibatch_step", theta_dev, grad_dev, m_dev, v_dev, obs_dev, act_dev, logp_dev,
+                                     val_dev, adv_dev, ret_dev, num_samples, perm_dev, first, mb, adv_stats_dev, cliprange, ent_coef,
+                                     vf_coef, lr, beta1, beta2, eps, max_grad_norm, 1.0f, 1, loss_sums_dev, stream, &b, &groups))
+    return rc;
+  hipLaunchKernelGGL(learn_adam_kernel, dim3(((p->lay.count >> 2) + 255) / 256), dim3(256), 0, (hipStream_t)stream, b, groups);
   HIP_TRY(hipGetLastError());
   return TREX_OK;
+}
+
+int trex_policy_minibatch_grad(TrexPolicy *p, const float *theta_dev, float *grad_dev, const float *obs_dev, const float *act_dev,
+                               const float *logp_dev, const float *val_dev, const float *adv_dev, const float *ret_dev,
+                               int64_t num_samples, const int64_t *perm_dev, int first, int mb, const float *adv_stats_dev,
+                               float cliprange, float ent_coef, float vf_coef, float grad_scale, float *loss_sums_dev, void *stream) {
+  if (!p) return trex_fail(TREX_E_INVALID, "trex_policy_minibatch_grad: null argument");
+  TrexDeviceGuard guard(p->device);
+  return launch_minibatch_grad(p, "trex_policy_minibatch_grad", const_cast<float *>(theta_dev), grad_dev, nullptr, nullptr, obs_dev,
+                               act_dev, logp_dev, val_dev, adv_dev, ret_dev, num_samples, perm_dev, first, mb, adv_stats_dev,
+                               cliprange, ent_coef, vf_coef, 0.f, 0.9f, 0.999f, 1e-5f, 0.f, grad_scale, 0, loss_sums_dev, stream,
+                               nullptr, nullptr);
 }
 
 }  // extern "C"

@@ -47,7 +47,7 @@ POLICY_SYMBOLS = [
     "trex_policy_create", "trex_policy_destroy", "trex_policy_param_count", "trex_policy_param_offsets",
     "trex_policy_get_stats", "trex_policy_set_stats", "trex_policy_get_returns", "trex_policy_observe",
     "trex_policy_act", "trex_policy_gae", "trex_policy_adam", "trex_policy_adam_reset",
-    "trex_policy_minibatch_stats", "trex_policy_minibatch_step",
+    "trex_policy_minibatch_stats", "trex_policy_minibatch_step", "trex_policy_minibatch_grad",
 ]
 
 _vp = C.c_void_p
@@ -117,6 +117,7 @@ lib.trex_policy_adam.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, 
 lib.trex_policy_adam_reset.argtypes = [_vp, _vp]
 lib.trex_policy_minibatch_stats.argtypes = [_vp, _vp, C.c_int64, _vp, C.c_int, C.c_int, _vp, _vp]
 lib.trex_policy_minibatch_step.argtypes = ([_vp] * 11 + [C.c_int64, _vp, C.c_int, C.c_int, _vp] + [C.c_float] * 8 + [_vp, _vp])
+lib.trex_policy_minibatch_grad.argtypes = ([_vp] * 9 + [C.c_int64, _vp, C.c_int, C.c_int, _vp] + [C.c_float] * 4 + [_vp, _vp])
 
 
 class TrexError(RuntimeError):
@@ -501,6 +502,17 @@ class Policy:
         check(lib.trex_policy_minibatch_stats(self.h, self._p(adv, N, "adv"), N, self._p(perm, num_minibatches * mb, "perm", "int64"),
                                               int(num_minibatches), int(mb), self._p(out, 2 * num_minibatches, "stats_out"),
                                               self._stream(stream)))
+
+    def minibatch_grad(self, theta, grad, obs, act, logp, val, adv, ret, perm, first, mb, adv_stats, cliprange=0.2, ent_coef=0.0,
+                       vf_coef=0.5, grad_scale=1.0, loss_sums=None, stream=None):
+        """The gradient of perm[first : first + mb] alone, times grad_scale (no clip, no Adam): the data-parallel trainer's
+        half of a minibatch step (include/trex_policy.h)."""
+        P, N, D, A = self.param_count, adv.numel(), self.D, self.A
+        check(lib.trex_policy_minibatch_grad(
+            self.h, self._p(theta, P, "theta"), self._p(grad, P, "grad"), self._p(obs, N * D, "obs"), self._p(act, N * A, "act"),
+            self._p(logp, N, "logp"), self._p(val, N, "val"), self._p(adv, N, "adv"), self._p(ret, N, "ret"), N,
+            self._p(perm, first + mb, "perm", "int64"), int(first), int(mb), self._p(adv_stats, 2, "adv_stats"), float(cliprange),
+            float(ent_coef), float(vf_coef), float(grad_scale), self._p(loss_sums, 2, "loss_sums"), self._stream(stream)))
 
     def minibatch_step(self, theta, grad, m, v, obs, act, logp, val, adv, ret, perm, first, mb, adv_stats, cliprange=0.2,
                        ent_coef=0.0, vf_coef=0.5, lr=3e-4, beta1=0.9, beta2=0.999, eps=1e-5, max_grad_norm=0.5, loss_sums=None,

@@ -65,6 +65,58 @@ class MlpPolicy(nn.Module):
         return self._mlp("vf", obs).squeeze(-1)
 
 
+def merge_running_moments(prefix, parts):
+    """VecNormalize's running statistics across data-parallel ranks. All ranks start a rollout with the SAME statistics
+    `prefix` = (mean, var, count); during the rollout rank r's statistics kernel folds in its own envs' observations and
+    ends with parts[r] = (mean_r, var_r, count_r). The statistics of everything seen - the prefix and every rank's new
+    data once - by Chan's parallel formula, in rank order (f64; the same on every rank):
+      new data of rank r: n_r = count_r - c0, mean and M2 by un-merging the prefix from rank r's statistics;
+      merged = prefix (+) new_0 (+) new_1 ...     with (a (+) b): delta = mean_b - mean_a, n = n_a + n_b,
+               mean = mean_a + delta n_b / n, M2 = M2_a + M2_b + delta^2 n_a n_b / n."""
+    import numpy as np
+    m0, v0, c0 = (np.asarray(x, np.float64) for x in prefix)
+    mean, M2, cnt = m0.copy(), v0 * c0, float(c0)
+    for mr, vr, cr in parts:
+        mr, vr, cr = np.asarray(mr, np.float64), np.asarray(vr, np.float64), float(cr)
+        nb = cr - float(c0)
+        if nb <= 0:
+            continue
+        mb_ = (cr * mr - c0 * m0) / nb                                   # mean of rank r's new data
+        M2b = vr * cr - v0 * c0 - (mb_ - m0) ** 2 * c0 * nb / cr         # its sum of squared deviations
+        delta = mb_ - mean
+        tot = cnt + nb
+        M2 = M2 + M2b + delta ** 2 * cnt * nb / tot
+        mean = mean + delta * nb / tot
+        cnt = tot
+    return mean, M2 / cnt, cnt
+
+
+def dp_minibatch_stats(adv, perm, nminibatches, mb, world, out, group=None):
+    """mean and 1 / (std + 1e-8) (population std) of the advantages of every GLOBAL minibatch - this rank's share
+    perm[k mb : (k + 1) mb) together with the other ranks' - from f64 sums, ONE all-reduce per epoch -> out [nminibatches, 2]."""
+    import torch.distributed as dist
+    a = adv[perm[: nminibatches * mb]].view(nminibatches, mb).double()
+    s = torch.stack([a.sum(1), (a * a).sum(1)], 1)
+    dist.all_reduce(s, group=group)
+    n = float(mb * world)
+    mean = s[:, 0] / n
+    var = (s[:, 1] / n - mean * mean).clamp_min(0.0)
+    out.copy_(torch.stack([mean, 1.0 / (var.sqrt() + 1e-8)], 1).float())
+
+
+def dp_minibatch_step(kern, theta, grad, m, v, srcs, perm, first, mb, stats_row, world, group=None, cliprange=0.2, ent_coef=0.0,
+                      vf_coef=0.5, lr=3e-4, max_grad_norm=0.5, loss_sums=None):
+    """One data-parallel minibatch step: this rank's gradient / ranks (trex_policy_minibatch_grad), summed over the ranks (the
+    one collective of the trainer: 21 112 floats), then global-norm clip + TF-form Adam on every rank (trex_policy_adam) - the
+    update of the concatenated minibatch, the same on every rank."""
+    import torch.distributed as dist
+    obs, act, logp0, val0, adv, ret = srcs
+    kern.minibatch_grad(theta, grad, obs, act, logp0, val0, adv, ret, perm, first, mb, stats_row, cliprange, ent_coef, vf_coef,
+                        1.0 / world, loss_sums)
+    dist.all_reduce(grad, group=group)
+    kern.adam(theta, grad, m, v, lr=lr, eps=1e-5, max_grad_norm=max_grad_norm)
+
+
 class PPO:
     def __init__(self, env, nsteps=32, nminibatches=32, noptepochs=4, gamma=0.99, lam=0.95, lr=3e-4,
                  cliprange=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, clip_obs=10.0, clip_rew=10.0,
@@ -77,6 +129,16 @@ class PPO:
         is capture-safe (tests/test_gpu_invariants.py)."""
         self.env = env
         self.dev = env.device
+        # DATA-PARALLEL (BASELINE config 3 on N GPUs; SURVEY 8e: "only PPO gradient all-reduce remains"): one process per GPU, env
+        # sharded as the env itself is (TrexVecEnv(rank=, world_size=)): every rank rolls out its own envs with its own replica of
+        # the policy; per minibatch step the ranks SUM their gradients (one all-reduce of the flat 21 112-float vector between the
+        # reduce launch and the Adam launch), per epoch the advantage statistics of the minibatches, per rollout the VecNormalize
+        # moments (Chan's formula) - so that every rank applies the update of the concatenated minibatch and keeps identical
+        # parameters and statistics. Unmeasured on more than one GPU (DESIGN.md 7).
+        self.rank, self.world = int(getattr(env, "rank", 0)), int(getattr(env, "world_size", 1))
+        self.group = getattr(env, "process_group", None)
+        if self.world > 1 and (use_graphs or not native_learner):
+            raise ValueError("the data-parallel trainer runs the native learner, eagerly (collectives inside a captured graph are not supported here)")
         self.nsteps, self.nminibatches, self.noptepochs = nsteps, nminibatches, noptepochs
         self.gamma, self.lam, self.cliprange, self.lr = gamma, lam, cliprange, lr
         self.ent_coef, self.vf_coef, self.max_grad_norm = ent_coef, vf_coef, max_grad_norm
@@ -92,6 +154,10 @@ class PPO:
         self.mb_stats = torch.zeros(nminibatches, 2, device=self.dev)
         self.loss_sums = torch.zeros(2, device=self.dev)
         self.total_env_steps = 0
+        if self.world > 1:      # same initial parameters everywhere (seeded above), different exploration noise per rank
+            import torch.distributed as dist
+            dist.broadcast(self.policy.theta.data, 0, group=self.group)
+            torch.manual_seed(seed + 1000003 * (self.rank + 1))
         T = nsteps
         self.noise = torch.empty(T, n, ad, device=self.dev)
         self.actions = torch.empty(n, ad, device=self.dev)
@@ -142,12 +208,43 @@ class PPO:
             self._rollout_graph.replay()
         else:
             self._rollout()
-        self.total_env_steps += T * n
+        self.total_env_steps += T * n * self.world
+        if self.world > 1:
+            self._merge_statistics()
         flat = lambda x: x.reshape(T * n, *x.shape[2:])
         raw = self.kern.get_stats()["raw_reward_sum"]            # (the one host read-back per rollout)
         mean_rew, self._raw_sum = (raw - self._raw_sum) / (T * n), raw
         return (flat(self.b_obs), flat(self.b_act), flat(self.b_logp), flat(self.b_val[:T]), flat(self.b_adv), flat(self.b_ret),
                 mean_rew)
+
+    def _merge_statistics(self):
+        """Once per rollout: every rank's VecNormalize moments (observations, returns) merged into the same statistics."""
+        import numpy as np
+        import torch.distributed as dist
+        st = self.kern.get_stats()
+        prev = getattr(self, "_stats_prefix", None)
+        mine = {k: st[k] for k in ("obs_mean", "obs_var", "obs_count", "ret_mean", "ret_var", "ret_count") if k in st}
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, mine, group=self.group)
+        if prev is None:      # first rollout: the statistics started from the reset's first observation on every rank
+            prev = dict(obs_mean=np.zeros_like(np.asarray(st["obs_mean"], np.float64)), obs_var=np.ones_like(np.asarray(st["obs_var"], np.float64)),
+                        obs_count=1e-4, ret_mean=0.0, ret_var=1.0, ret_count=1e-4)
+        om, ov, oc = merge_running_moments((prev["obs_mean"], prev["obs_var"], prev["obs_count"]),
+                                           [(e["obs_mean"], e["obs_var"], e["obs_count"]) for e in everyone])
+        st.update(obs_mean=om, obs_var=ov, obs_count=oc)
+        if "ret_count" in mine:
+            rm, rv, rc = merge_running_moments((prev["ret_mean"], prev["ret_var"], prev["ret_count"]),
+                                               [(e["ret_mean"], e["ret_var"], e["ret_count"]) for e in everyone])
+            st.update(ret_mean=float(rm), ret_var=float(rv), ret_count=rc)
+        self.kern.set_stats(st)
+        self._stats_prefix = {k: (np.array(st[k], np.float64) if hasattr(st[k], "__len__") else float(st[k])) for k in mine}
+
+    def _dp_minibatch_stats(self, adv, perm, mb):
+        dp_minibatch_stats(adv, perm, self.nminibatches, mb, self.world, self.mb_stats, self.group)
+
+    def dp_minibatch_step(self, srcs, perm, first, mb, stats_row):
+        dp_minibatch_step(self.kern, self.policy.theta, self.policy.grad, self.adam_m, self.adam_v, srcs, perm, first, mb, stats_row,
+                          self.world, self.group, self.cliprange, self.ent_coef, self.vf_coef, self.lr, self.max_grad_norm, self.loss_sums)
 
     def _loss(self, obs, act, logp0, val0, adv, ret):
         a = (adv - adv.mean()) / (adv.std(unbiased=False) + 1e-8)       # numpy's std: population
@@ -174,8 +271,16 @@ class PPO:
         if self.native_learner:
             obs, act, logp0, val0, adv, ret = srcs
             k, pol = self.kern, self.policy
-            k.minibatch_stats(adv, perm, self.nminibatches, mb, self.mb_stats)
             self.loss_sums.zero_()
+            if self.world > 1:
+                self._dp_minibatch_stats(adv, perm, mb)
+                for i in range(self.nminibatches):
+                    self.dp_minibatch_step(srcs, perm, i * mb, mb, self.mb_stats[i])
+                import torch.distributed as dist
+                dist.all_reduce(self.loss_sums, group=self.group)
+                ent = (pol.logstd.detach() + 0.5 * (math.log(2 * math.pi) + 1.0)).sum() * self.nminibatches
+                return torch.cat([self.loss_sums, ent.reshape(1)])
+            k.minibatch_stats(adv, perm, self.nminibatches, mb, self.mb_stats)
             for i in range(self.nminibatches):
                 k.minibatch_step(pol.theta, pol.grad, self.adam_m, self.adam_v, obs, act, logp0, val0, adv, ret, perm, i * mb, mb,
                                  self.mb_stats[i], self.cliprange, self.ent_coef, self.vf_coef, self.lr, 0.9, 0.999, 1e-5,
