@@ -236,16 +236,21 @@ struct ObserveArgs {
 // One workgroup = OBS_ROWS rows x 4 row groups of 128 threads (thread c of a group: column c); every thread takes 8 rows
 // per trip with the 8 loads in flight together. (Version 1 walked 64 rows one dependent load after the other and merged
 // 64 partials the same way: 48 us per launch.)
+// TWO launches since round 4 (MERGE = false: the per-workgroup partial sums; MERGE = true, one workgroup: their merge in
+// workgroup order and the update of the running statistics). As ONE launch whose last workgroup to end did the merge - two
+// device-scope fences, an atomic hand-over and a workgroup that starts its second job only when the slowest has ended - this
+// took 24 us for 1.26 MB.
 constexpr int OBS_GROUPS = 4;
-__global__ __launch_bounds__(128 * OBS_GROUPS) void observe_kernel(ObserveArgs g) {
+template <bool MERGE>
+__global__ __launch_bounds__(128 * OBS_GROUPS) void observe_kernel(ObserveArgs g, int G) {
   __shared__ double red[OBS_GROUPS][128][3];
-  __shared__ bool last;
-  const int tid = threadIdx.x, c = tid & 127, grp = tid >> 7, D = g.D, G = gridDim.x;
+  const int tid = threadIdx.x, c = tid & 127, grp = tid >> 7, D = g.D;
+  double s = 0.0, ss = 0.0, sr = 0.0;
+  if (!MERGE) {
   const int per = OBS_ROWS / OBS_GROUPS;
   const int r0 = blockIdx.x * OBS_ROWS + grp * per, r1 = min(r0 + per, g.n);
   // thread c < D: observation column c. thread D: the discounted returns (+ the raw rewards, for logging).
   // Sums are taken about the RUNNING mean (a shift that every workgroup knows): no cancellation in the variance.
-  double s = 0.0, ss = 0.0, sr = 0.0;
   if (c < D) {
     for (int r = r0; r < r1; r += 16) {       // 16 rows per row group: ONE trip
       float x[16];
@@ -289,15 +294,10 @@ __global__ __launch_bounds__(128 * OBS_GROUPS) void observe_kernel(ObserveArgs g
     p[0] = a; p[1] = b;
     if (c == D) { p[2] = d; p[3] = 0.0; }
   }
-  // ---- the last workgroup to end merges the partials, in workgroup order (fixed: deterministic)
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) last = atomicAdd(g.counter, 1u) == (unsigned)(G - 1);
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
+  return;
+  }
+  // ---- MERGE: the partials in workgroup order (fixed: deterministic)
   // row group q sums the workgroups q, q + 4, ... (8 loads in flight per trip), then group 0 adds the four in order
-  s = 0.0; ss = 0.0; sr = 0.0;
   if (c <= D) {
     for (int w = grp; w < G; w += 8 * OBS_GROUPS) {
       double a[8], b[8], d[8];
@@ -341,7 +341,6 @@ __global__ __launch_bounds__(128 * OBS_GROUPS) void observe_kernel(ObserveArgs g
   if (tid == 0) {   // counts last: every column read the old one above
     g.stats[2 * D] += (double)g.n;
     if (g.with_reward) g.stats[2 * D + 3] += (double)g.n;
-    *g.counter = 0u;
   }
 }
 
@@ -548,7 +547,8 @@ int trex_policy_observe(TrexPolicy *p, const float *rows_dev, int row_stride, in
   BUF_TRY(rew_scale_out, sizeof(float), "trex_policy_observe: rew_scale_out");
   ObserveArgs a{rows_dev, p->stats, p->partial, p->norm, p->ret, raw_rew_out, done_out, rew_scale_out, p->counter,
                 p->n, row_stride, p->D, with_reward ? 1 : 0, gamma, p->epsilon};
-  hipLaunchKernelGGL(observe_kernel, dim3(p->G), dim3(128 * OBS_GROUPS), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(observe_kernel<false>, dim3(p->G), dim3(128 * OBS_GROUPS), 0, (hipStream_t)stream, a, p->G);
+  hipLaunchKernelGGL(observe_kernel<true>, dim3(1), dim3(128 * OBS_GROUPS), 0, (hipStream_t)stream, a, p->G);
   HIP_TRY(hipGetLastError());
   return TREX_OK;
 }
