@@ -547,6 +547,7 @@ def main():
         kernel_ms_ranks = km.tolist()
     finite = bool(torch.isfinite(many_rows if S > 1 else env.obs).all().item())
     info = env.batch.launch_info()
+    step_kernel = "trex_step_pair_kernel" if info["block"] == 128 else "trex_step_kernel<false, false>"
     build_id = _capi.build_id()
     if rank == 0:
         alg = (info["alg_bytes_per_env_step"] + (1044 if args.domain_rand else 0)) * n_local  # bytes per launch
@@ -604,8 +605,8 @@ def main():
                        **({"ABLATION_param_overrides": overrides} if overrides else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel": "trex_step_many_kernel" if S > 1 else "trex_step_kernel<false, false>", "kernel_ms": kernel_ms,
-                         "kernel_ms_covers": "one step launch = ONE kernel, trex_step_kernel<false, false> (it ranks the envs for the next launch and "
+                         "kernel": "trex_step_many_kernel" if S > 1 else step_kernel, "kernel_ms": kernel_ms,
+                         "kernel_ms_covers": "one step launch = ONE kernel, " + step_kernel + " (it ranks the envs for the next launch and "
                                              "resets the envs whose episode ends); " + ("ONE pair of HIP events spans launches 2 .. %d of the timed region (back-to-back on the stream): elapsed / %d" % (args.steps, args.steps - 1)
                                                                                      if span_events else "every %d-th launch of the timed region is bracketed by HIP events (%d samples)" % (stride, len(sampled))),
                          "alg_bytes_per_launch": alg, "kernel_build": build_id,

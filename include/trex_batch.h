@@ -228,7 +228,9 @@ int trex_batch_contact_stats(TrexBatch *batch, int32_t *count_dev, float *normal
  * lambda(3), [1216+32(3c+a) ..) the contact rows' response vectors. Not part of the product path. */
 int trex_batch_debug_step(TrexBatch *batch, const float *actions_dev, float *obs_dev, float *debug_dev, void *stream);
 
-/* Launch geometry + bytes, for bench.py: fills grid, block, lds bytes, algorithmic bytes/env-step. */
+/* Launch geometry + bytes, for bench.py: fills grid, block, lds bytes, algorithmic bytes/env-step. block = 128 means the
+ * pair form of the step launch (two envs = two wavefronts per workgroup: even batches of at most 4096 envs), 64 the
+ * single-env form. */
 int trex_batch_launch_info(const TrexBatch *batch, int *grid, int *block, int *lds_bytes,
                            int *alg_bytes_per_env_step);
 

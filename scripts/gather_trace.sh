@@ -4,7 +4,7 @@ f=$(ls gpurun_out/rg/*/*_kernel_trace.csv | head -1)
 python - "$f" <<'PY'
 import csv,sys
 rows=sorted(csv.DictReader(open(sys.argv[1])), key=lambda r:int(r["Start_Timestamp"]))
-steps=[i for i,r in enumerate(rows) if "trex_step_kernel<false, false>" in r["Kernel_Name"]]
+steps=[i for i,r in enumerate(rows) if ("trex_step_kernel<false, false>" in r["Kernel_Name"] or "trex_step_pair_kernel" in r["Kernel_Name"])]
 i0=steps[-30]
 t0=int(rows[i0]["Start_Timestamp"])
 for r in rows[i0:i0+12]:

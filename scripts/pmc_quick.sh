@@ -5,7 +5,7 @@ import csv,glob,collections
 f=max(glob.glob("gpurun_out/ic/**/*_counter_collection.csv", recursive=True))
 per=collections.defaultdict(lambda: collections.defaultdict(float))
 for r in csv.DictReader(open(f)):
-    if "trex_step_kernel<false, false>" in r["Kernel_Name"]:
+    if ("trex_step_kernel<false, false>" in r["Kernel_Name"] or "trex_step_pair_kernel" in r["Kernel_Name"]):
         per[r["Counter_Name"]][r["Dispatch_Id"]]+=float(r["Counter_Value"])
 for c,dd in per.items():
     vals=[dd[k] for k in sorted(dd,key=int)][-40:]

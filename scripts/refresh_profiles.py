@@ -19,9 +19,8 @@ os.chdir(ROOT)
 tag, out = sys.argv[1], sys.argv[2]
 os.makedirs(out, exist_ok=True)
 P = "gpurun_out/prof"
-KERNEL = "trex_step_kernel<false, false>"
-
 line = json.loads([l for l in open(P + "/bench_trace.json") if l.startswith("{")][-1])
+KERNEL = line["roofline"].get("kernel", "trex_step_kernel<false, false>")     # trex_step_pair_kernel since round 4 (even resident batches)
 build = line["roofline"]["kernel_build"]
 
 # ---- kernel trace

@@ -14,7 +14,7 @@ for d in sys.argv[2:]:
     for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
         per = collections.defaultdict(lambda: collections.defaultdict(float))
         for r in csv.DictReader(open(f)):
-            if "trex_step_kernel<false, false>" in r["Kernel_Name"]:
+            if "trex_step_kernel<false, false>" in r["Kernel_Name"] or "trex_step_pair_kernel" in r["Kernel_Name"]:
                 per[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
                 for k in ("VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size", "Accum_VGPR_Count"):
                     if k in r:

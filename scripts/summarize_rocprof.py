@@ -23,11 +23,17 @@ def main():
         lines.append("| %s | %s | %.2f | %.1f | %s | %.1f | %.1f |" % (
             name, r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, r["Percentage"],
             float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
-    t = [r for r in csv.DictReader(open(trace)) if "trex_step_kernel<false, false>" in r["Kernel_Name"]]
+    kname = "trex_step_kernel<false, false>"
+    if bench_json:      # the traced bench line names the step launch's kernel (trex_step_pair_kernel for even resident batches)
+        try:
+            kname = json.loads([l for l in open(bench_json) if l.startswith("{")][-1])["roofline"].get("kernel", kname)
+        except Exception:  # noqa: BLE001
+            pass
+    t = [r for r in csv.DictReader(open(trace)) if kname in r["Kernel_Name"]]
     t.sort(key=lambda r: int(r["Start_Timestamp"]))
     d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in t]
     timed = d[-steps:]
-    lines += ["", "step kernel `trex_step_kernel<false, false>`: %d dispatches; timed region (last %d): avg %.3f ms, min %.3f, max %.3f"
+    lines += ["", "step kernel `" + kname + "`: %d dispatches; timed region (last %d): avg %.3f ms, min %.3f, max %.3f"
               % (len(d), len(timed), sum(timed) / len(timed) / 1e6, min(timed) / 1e6, max(timed) / 1e6)]
     pk = [r for r in csv.DictReader(open(trace)) if "trex_balance_kernel" in r["Kernel_Name"]]
     if not pk:

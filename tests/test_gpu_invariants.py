@@ -193,8 +193,11 @@ def test_launch_info_and_event_timing(capi=None):
     v = TrexVecEnv(1000, urdf_path=ASSET_URDF, device=DEV)
     v.reset_tensor()
     info = v.batch.launch_info()
-    assert info["grid"] == 1000 and info["block"] == 64 and info["alg_bytes_per_env_step"] == 912   # one env per wave
-    assert 0 < info["lds_bytes"] <= 10 * 1024          # 16 workgroups per CU (4 waves per SIMD) must fit the 160 KB of LDS
+    # an even batch of at most 4096 envs: the pair form, two envs = two waves per workgroup (one env per WAVE either way)
+    assert info["grid"] == 500 and info["block"] == 128 and info["alg_bytes_per_env_step"] == 912
+    assert 0 < info["lds_bytes"] <= 20 * 1024          # 8 two-env workgroups per CU (4 waves per SIMD) must fit the 160 KB of LDS
+    odd = TrexVecEnv(999, urdf_path=ASSET_URDF, device=DEV).batch.launch_info()
+    assert odd["grid"] == 999 and odd["block"] == 64 and 0 < odd["lds_bytes"] <= 10 * 1024      # the single-env form
     ms = v.batch.time_steps(torch.zeros(1000, 25, device=DEV), torch.zeros(1000, 75, device=DEV),
                             torch.zeros(1000, device=DEV), torch.zeros(1000, dtype=torch.uint8, device=DEV), 5)
     assert 0.05 < ms < 50

@@ -29,8 +29,8 @@ hipError_t trex_launch_scalars_get(TrexBatchArrays, int, int32_t *, float *, int
 hipError_t trex_launch_scalars_set(TrexBatchArrays, int, const int32_t *, int, int, hipStream_t);
 hipError_t trex_launch_fill_u8(uint8_t *, uint8_t, int, hipStream_t);
 hipError_t trex_launch_copy_mass_scale(const float *, float *, int, int, hipStream_t);
-int trex_step_lds_bytes(void);
-int trex_step_envs_per_workgroup(void);
+int trex_step_lds_bytes(int);
+int trex_step_envs_per_workgroup(int);
 }
 
 struct TrexModel {
@@ -123,6 +123,16 @@ void fill_device_model(const trex::HostModel &h, TrexDeviceModel &d) {
     d.hull_start[b] = h.hull_start[b];
   }
   for (int b = h.nb; b <= TREX_TL; b++) d.hull_start[b] = h.hull_start[h.nb];
+  {
+    int off = 0;
+    for (int b = 0; b < TREX_TL; b++) {
+      const int nv = b < h.nb ? h.hull_start[b + 1] - h.hull_start[b] : 0;
+      int lg = nv == 0 ? 0 : (nv <= 256 ? 3 : (nv <= 1024 ? 5 : 0));
+      if (lg && off + (1 << lg) > TREX_CM_WORDS) lg = 0;          // no room left: this body is swept, not masked
+      d.cm_pack[b] = (off << 8) | lg;
+      if (lg) off += 1 << lg;
+    }
+  }
   {
     // scan units: the hull groups if they nest in the bodies' vertex ranges and are at most 32, else one per body
     std::vector<std::array<int, 3>> units;   // body, v0, v1
@@ -695,10 +705,10 @@ int trex_batch_contact_stats(TrexBatch *b, int32_t *count_dev, float *normal_imp
 
 int trex_batch_launch_info(const TrexBatch *b, int *grid, int *block, int *lds_bytes, int *alg_bytes_per_env_step) {
   if (!b) return fail(TREX_E_INVALID, "null batch");
-  const int epw = trex_step_envs_per_workgroup();
+  const int epw = trex_step_envs_per_workgroup(b->n);
   if (grid) *grid = (b->n + epw - 1) / epw;
-  if (block) *block = 64;
-  if (lds_bytes) *lds_bytes = trex_step_lds_bytes();
+  if (block) *block = 64 * epw;       // one wavefront per env
+  if (lds_bytes) *lds_bytes = trex_step_lds_bytes(b->n);
   // state in + out (13 + 2J floats each), action in (J), obs out (3J), reward (4 B), done (padded 4 B): SURVEY 8d
   if (alg_bytes_per_env_step) *alg_bytes_per_env_step = 4 * (2 * (13 + 2 * b->nj) + b->nj + 3 * b->nj + 1 + 1);
   return TREX_OK;

@@ -5,6 +5,7 @@
 #define TREX_TL 32        /* lanes per env team = half a wavefront */
 #define TREX_MAXD 6       /* tree depth supported */
 #define TREX_MAXCH 4      /* moving children per body */
+#define TREX_CM_WORDS 320  /* mask words per env: 32 for one big body + 8 for every other (T-rex: 216) */
 #define TREX_MAXC 13      /* contact points kept per env: 25 motor rows + 3 x 13 contact rows = 64 lanes */
 
 enum TrexParam {
@@ -30,6 +31,10 @@ struct TrexDeviceModel {
   int child[TREX_MAXCH][TREX_TL];     /* moving children of body b, -1 = none */
   unsigned desc_mask[TREX_TL];        /* per DOF LANE: bit b set if body b's chain contains this dof (base dof lanes: all bodies) */
   int hull_start[TREX_TL + 1];
+  /* In-margin vertex masks of the contact generation (LDS): body b owns 2^log words from word `off` on, word w holding the
+   * vertices w, w + 2^log, ... of the body (bit j <-> vertex 2^log j + w): log = 3 for a body of at most 256 hull vertices,
+   * 5 up to 1024, 0 = no mask (a larger body, or no room left: swept instead). cm_pack[b] = off << 8 | log. */
+  int cm_pack[TREX_TL];
   float axis[3][TREX_TL], jpos[3][TREX_TL], jrot[9][TREX_TL], com[3][TREX_TL], inertia[6][TREX_TL];
   float mass[TREX_TL], lower[TREX_TL], upper[TREX_TL], damp[TREX_TL], q_start[TREX_TL];
   float sphere[4][TREX_TL];           /* bounding sphere of the body's hull vertices: cx cy cz r */

@@ -6,8 +6,9 @@
 // (trex_env.py:186-196); with RESET: TrexBulletEnv.reset() (trex_env.py:98-122).
 //
 // Mapping to the hardware
-//   * ONE ENV PER 64-LANE WAVEFRONT, one wavefront per workgroup, at most 128 registers per lane and
-//     10 KB of LDS per workgroup: 4 waves per SIMD (16 per CU), so that at the headline 4096 envs every
+//   * ONE ENV PER 64-LANE WAVEFRONT - one wavefront per workgroup, or two envs = two wavefronts per workgroup with split roles in
+//     the middle of a substep (PAIR, below: the step launch of even batches up to 4096 envs) -, at most 128 registers per lane and
+//     under 10 KB of LDS per env: 4 waves per SIMD (16 per CU), so that at the headline 4096 envs every
 //     env is resident at once (4096 waves = 1024 SIMDs x 4) and the serial Gauss-Seidel chain of one env
 //     hides behind the three other waves of its SIMD. No inter-wave synchronisation exists.
 //   * lanes 0..25 = the 26 bodies (lane b = body b = joint b) for the tree sweeps; for the constraint
@@ -49,6 +50,9 @@
 
 #ifndef TREX_STAMPS
 #define TREX_STAMPS 0
+#endif
+#ifndef TREX_PAIR_LAUNCH
+#define TREX_PAIR_LAUNCH (!TREX_STAMPS)      // 0: every batch through the single-env launch (A/B builds; the stamped diagnostic build)
 #endif
 // diagnostic variants for scripts/parity_ablation.sh (which round-2 arithmetic shortcut costs what in one-step error)
 #ifndef TREX_ABLATE_EXACT_MATH
@@ -326,21 +330,26 @@ constexpr int BREC = 5;                  // float4s per record
 struct WaveLds {
   float4 body[32 * BREC];     // 2560 B; after the row walks: z0 stash [6][64] for the base twist change
   union {
-    float aba[32][28];        // tip-to-base pass: articulated inertia (21) + bias force (6) per body      3584 B
+    struct {
+      float aba[32][28];      // tip-to-base pass: articulated inertia (21) + bias force (6) per body      3584 B
+      float rtab[32][9];      // PAIR launches: body rotations, handed to the wave that runs the tree phases 1152 B
+    } t;
     float4 desc[64][4];       // B build: column descriptor of the row on lane L: chain | zc[6] | z0[6]     4096 B
-    float4 cg[336];           // contact generation: CgLds (below)                                          5376 B
+    float4 cg[160];           // contact generation (single-env launches): CgLds (below)                     2560 B
   } u;
   float cpt[MAXC][8];         // contact points: body, x, y, z (rel. base origin), distance     416 B
   float st[6][TL];            // per body lane, parked across the phases: q, qd, motor torque, target, updated rate, 1/M^-1_jj  768 B
+  float xch[44];              // PAIR launches, between the two waves of a workgroup: [0..5] base twist w, v | [6] env | [7] substeps
+                              // of this step | [8..28] Cholesky factor of the base's articulated inertia | [29..34] base acceleration
 };
 enum { ST_Q, ST_QD, ST_TAU, ST_TARGET, ST_NQD, ST_MDG };
-static_assert(sizeof(WaveLds) <= 10240, "16 workgroups per CU need <= 10 KB of LDS each");
+static_assert(sizeof(WaveLds) <= 10240, "16 envs per CU need <= 10 KB of LDS each");
 // Contact generation works in the union area (the inertia slots are written after it):
-constexpr int CG_WORDS = 32;             // in-margin mask words per body: bit j of word w <-> vertex 32 j + w of the body (up to 1024)
+constexpr int CG_WORDS = TREX_CM_WORDS;  // in-margin mask words per ENV, packed per body (device_model.h: cm_pack)
 struct CgLds {
   unsigned long long best[TL];           // per body: min of (ordered distance << 32 | vertex)                256 B
   float4 ent[TL][2];                     // near-hull table: end position | vertex - position | body | body v0 ; Rz, zb  1024 B
-  unsigned cm[TL][CG_WORDS];             // per body: word w, bit j <-> vertex hull_start[body] + 32 j + w inside the margin   4096 B
+  unsigned cm[CG_WORDS];                 // per body b, from word cm_pack[b] >> 8: word w, bit j <-> vertex hull_start[b] + P j + w inside the margin, P = 8 or 32   1280 B
 };
 static_assert(sizeof(CgLds) <= sizeof(WaveLds::u), "contact-generation scratch fits the union area");
 
@@ -377,16 +386,38 @@ struct KernelArgs {
 // that draw env after env off the rank lists through an atomic cursor, heaviest first. Bitwise the same rows; 10.7 M env-steps/s
 // at 8192 envs and 13.0 M at 32768 against 11.4 M / 13.3 M for one workgroup per env: the dispatcher refills the slots at
 // least as well, and the env loop around this body made the compiler hoist constants out of it - 7 spilled registers.)
-// (Measured in round 4 and NOT kept - DESIGN.md 6, git history "EXPERIMENT ... two envs per workgroup": the four lane-per-body tree
-// phases - velocities / inertias / bias forces, ABA pass 2, the base's Cholesky factor, ABA pass 3: a fifth of a wave's cycles at
-// 26 of 64 lanes - run ONCE for the two envs of a two-wave workgroup, lanes 0..31 / 32..63, the partner wave waiting at a
-// barrier. Same rows up to rounding; 11.40 M against 11.53 M env-steps/s at 4096 envs and the heaviest env alone 0.298 against
-// 0.288 ms: two workgroup barriers per substep, the lockstep of two envs of different length and the hand-over of rotations,
-// twists and the base factor through LDS cost more than halving the instruction stream of those phases gives back.)
-template <bool RESET, bool DEBUG, bool MULTI>
-__device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int wg) {   // wg: blockIdx.x
-  __shared__ WaveLds W;
-  const int tid = threadIdx.x;
+// PAIR (trex_step_pair_kernel, the step launch of an even batch of at most 4096 envs): a workgroup of TWO waves = two envs, a
+// HEAVY one (wave 0: rank p from the heavy end of the rank lists) and a LIGHT one (wave 1: rank n - 1 - p). Kinematics, row walks,
+// B build, sweeps and integration stay per wave, each for its own env. In between the two waves split ROLES, each working
+// for BOTH envs at the same time:
+//   wave 1  generates the contacts of env 0, then of env 1 (64 lanes each; the body rotations, origins and the base height come
+//           from LDS, its scratch is the workgroup's);
+//   wave 0  runs the four phases that work with one lane per BODY - velocities / inertias / bias forces, ABA pass 2, the base's
+//           Cholesky factor, ABA pass 3: a fifth of a wave's cycles with 26 of 64 lanes busy - ONCE for both envs: lanes 0..31
+//           the bodies of its own env, lanes 32..63 those of its partner's, every LDS address and shuffle source offset by the half.
+// A substep loses the SHORTER of the two phases from its critical path (the single-env launch runs them one after the other)
+// and the instruction stream of the tree phases is issued once for two envs; it pays two workgroup barriers, the hand-over of
+// rotations, twists and the base factor through LDS, and the wait of the env that is done first - which is why the pairs are
+// heavy + light: the wave that generates contacts does it for both envs one after the other, and two contact-heavy envs in one
+// workgroup leave nothing of the overlap (round 4, first form: the partner merely WAITED during the tree phases - 11.40 M against
+// 11.53 M; roles with adjacent ranks paired +1.7 % at 2048 envs, heavy + light +7.7 %; at 4096 envs, where four waves share a
+// SIMD, 11.70 M against 11.50 M). The same arithmetic per lane: BITWISE the rows of the single-env launch (scripts/state_digest.py,
+// 300 steps of 4096 envs; the test-suite compares even batches - this form - with step_many, resets and odd batches - that form).
+#define WSYNC() do { if (PAIR) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); else __syncthreads(); } while (0)
+template <bool RESET, bool DEBUG, bool MULTI, bool PAIR = false>
+__device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int wg_in) {   // wg_in: blockIdx.x
+  static_assert(!PAIR || (!RESET && !DEBUG && !MULTI), "the pair form exists for the product step launch only");
+  __shared__ WaveLds Wpair[PAIR ? 2 : 1];
+  __shared__ __attribute__((aligned(16))) unsigned char Gpair[PAIR ? sizeof(CgLds) : 16];   // PAIR: contact-generation scratch of the workgroup (wave 1)
+  const int wave = PAIR ? uni((int)threadIdx.x >> 6) : 0;
+  // (PAIR: the LDS of this wave's env is addressed through ONE base register the compiler takes for lane-dependent - a
+  // wave-uniform base made it precompute an address per access as scalars: 226 spilled scalar registers, 80 reloads in the
+  // B build alone)
+  int wave_v = PAIR ? (int)threadIdx.x >> 6 : 0;
+  if (PAIR) asm volatile("" : "+v"(wave_v));
+  WaveLds &W = Wpair[wave_v];
+  const int wg = PAIR ? 2 * wg_in + wave : wg_in;       // the index the env-to-wave deal and the priorities go by
+  const int tid = (int)threadIdx.x & 63;
   const TrexDeviceModel *__restrict__ M = args.model;
   // Which env this wave runs. All waves of the headline launch are resident at once and a SIMD is done when its
   // slowest wave is, so the envs are dealt by the contact count of their PREVIOUS step launch: every wave filed its
@@ -403,9 +434,18 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
     const int32_t *cnt = B + TREX_BAL_COUNTS + TREX_BAL_BINS * bal_phase;
     const int k = wg, q = k >> 10, m = min(1024, args.n_envs - (q << 10));
     int r = q == 0 ? k : (q << 10) + (m - 1 - (k & 1023));
+    if (PAIR) {
+      // a workgroup pairs a HEAVY env with a LIGHT one: wave 0 takes rank p from the heavy end, wave 1 rank n - 1 - p from the
+      // light end. The wave that generates the contacts does it for both envs one after the other, beside the tree dynamics of
+      // both: two contact-heavy envs in one workgroup would leave nothing of the overlap. Workgroups b, b + 512, ... share a
+      // SIMD pair: pair indices go to them like ranks go to single-env workgroups - first block in order, later blocks reversed.
+      const int bq = wg_in >> 9, half = args.n_envs >> 1, bm = min(512, half - (bq << 9));
+      const int pidx = bq == 0 ? wg_in : (bq << 9) + (bm - 1 - (wg_in & 511));
+      r = wave == 0 ? pidx : args.n_envs - 1 - pidx;
+    }
     // (not better, measured: SIMD j taking rank j and the 3 LIGHTEST envs still to be dealt - 11.07 M against 11.13 M
     // at 4096 envs, 13.02 M against 13.18 M at 32768: which light mates a heavy wave has does not matter)
-    const int lane_ = (int)threadIdx.x;
+    const int lane_ = tid;
     const int mine = lane_ < TREX_BAL_BINS ? cnt[lane_] : 0;   // the 16 counts in one load, lane c holds count c
     int b = TREX_BAL_BINS - 1, total = 0;
 #pragma unroll
@@ -502,7 +542,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
       W.st[ST_NQD][tid] = 0.f;
     }
   }
-  __syncthreads();
+  WSYNC();
   const int n_sub = RESET ? (do_reset ? 1 : 0) : M->n_substeps;
   // Wave priority: the launch lasts as long as its slowest wave, and with one env per wave that is an env with
   // many contact rows. During its sweeps such a wave wins the issue arbitration against the lighter waves of
@@ -657,7 +697,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
       W.st[ST_Q][l] = l < nb ? Mo()->q_start[l] : 0.f;
       W.st[ST_QD][l] = 0.f; W.st[ST_TAU][l] = 0.f;
     }
-    __syncthreads();
+    WSYNC();
   };
   const int n_launch_steps = MULTI ? args.n_steps : 1;
 #pragma unroll 1
@@ -683,28 +723,39 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
     time_up = age >= args.arr.max_episode_steps;
   }
   const int n_total = n_sub + ((!RESET && time_up) ? 1 : 0);
+  int n_loop = n_total;
+  int nt_pair[2] = {n_total, n_total};
+  if (PAIR) {   // the two envs of the workgroup run the same number of loop trips (an env whose episode ends takes one more substep)
+    if (lane_id() == 0) W.xch[7] = __int_as_float(n_total);
+    __syncthreads();
+    nt_pair[0] = uni(__float_as_int(Wpair[0].xch[7])); nt_pair[1] = uni(__float_as_int(Wpair[PAIR ? 1 : 0].xch[7]));
+    n_loop = max(nt_pair[0], nt_pair[1]);
+  }
 #pragma unroll 1
-  for (int sub = 0; sub < n_total; sub++) {
-    if (!RESET && sub == n_sub) {   // time is up: the step is complete, the new episode starts (settle substep follows)
-      finish_step();
-      to_start_pose();
-      motors_on = false;            // remove_joint_control, trex_robot.py:309
-    }
+  for (int sub = 0; sub < n_loop; sub++) {
     // lane id and what derives from it are RE-derived at the start of every phase (RELANE): a value that
     // lived from the top of the substep would be spilled across the phases in between
     int lt, bl;                        // bl: index into the [32]-wide model / state rows (lanes >= 32 alias, never used)
     bool is_body, is_joint;
 #define RELANE() do { lt = lane_id(); bl = lt & (TL - 1); is_body = lt < nb; is_joint = lt >= 1 && lt < nb; } while (0)
-    RELANE();
     int psrc, depth;
+    float R[9], r[3];
+    float Sa[3], dpar[3];   // joint axis (world) and offset from the parent's origin: re-read from the record per phase
+    int nc = 0;
+    const bool act = !PAIR || sub < n_total;   // (PAIR: a wave whose env is done with this step only keeps the barriers)
+    if (act) {
+    if (!RESET && sub == n_sub) {   // time is up: the step is complete, the new episode starts (settle substep follows)
+      finish_step();
+      to_start_pose();
+      motors_on = false;            // remove_joint_control, trex_robot.py:309
+    }
+    RELANE();
     {
       const TrexDeviceModel *Mi = Mo();
       const int parent = is_body ? Mi->parent[bl] : 0;
       psrc = parent < 0 ? 0 : parent;
       depth = is_body ? Mi->depth[bl] : -1;
     }
-    float R[9], r[3];
-    float Sa[3], dpar[3];   // joint axis (world) and offset from the parent's origin: re-read from the record per phase
     {
       float dpar0[3], Sa0[3];
       forward_kinematics(lt, psrc, depth, R, r, dpar0, Sa0);
@@ -731,7 +782,42 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
                       dpar[0] = q4_.x; dpar[1] = q4_.y; dpar[2] = q4_.z; } while (0)
 #define RETREE() do { const int lk_ = __float_as_int(reinterpret_cast<const float *>(&W.body[BREC * bl + 3])[2]); \
                       psrc = lk_ & 255; depth = is_body ? (lk_ >> 8) : -1; } while (0)
+    if (PAIR) {   // hand this env's rotations, base twist and base height to the workgroup's LDS
+      const int l_ = lane_id();
+      if (l_ < TL) {
+        float *rt = W.u.t.rtab[l_];
+#pragma unroll
+        for (int c = 0; c < 9; c++) rt[c] = R[c];
+      }
+      if (l_ == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { W.xch[c] = bw[c]; W.xch[3 + c] = bv[c]; }
+        W.xch[6] = __int_as_float(env);
+        W.xch[36] = pos[2];
+      }
+    }
+    }   // act (kinematics)
     STAMP(0);
+    if (PAIR) __syncthreads();      // both envs' body records, state rows, rotations, twists and heights are in LDS
+    // (measured, not kept: both waves at the priority of the pair's heavier env between the two barriers - 11.69 against 11.67 M
+    // at 4096 envs, 6.73 against 6.94 M at 2048)
+    // ROLES (PAIR): wave 1 generates the contacts of BOTH envs, one after the other, WHILE wave 0 runs the lane-per-body
+    // dynamics of both (below): neither waits for the other's phase, a substep loses the shorter of the two
+    if (!PAIR || wave == 1) {
+    for (int e = 0; e < (PAIR ? 2 : 1); e++) {
+    if (PAIR && !(sub < nt_pair[e])) continue;
+    WaveLds &E = Wpair[PAIR ? e : 0];
+    float posz = pos[2];
+    if (PAIR) {
+      RELANE();
+      posz = E.xch[36];
+      if (lt < TL) {
+#pragma unroll
+        for (int c = 0; c < 9; c++) R[c] = E.u.t.rtab[lt][c];
+        const float4 q1_ = E.body[BREC * lt + 1];
+        r[0] = q1_.x; r[1] = q1_.y; r[2] = q1_.z;
+      }
+    }
 
     // ================================================================ contact generation
     // hull vertices against z <= floor_z. Pass A finds, per body, WHICH vertices are inside the margin (bit masks
@@ -745,18 +831,18 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
     //     the lowest vertex index, as in the oracle.
     // Pass B revisits a body's in-margin vertices only when more than one point per body is kept (K >= 2).
     // The points go to LDS (W.cpt) in contact order; only their number nc stays in a register.
-    int nc = 0;
+    nc = 0;
     {
       const TrexDeviceModel *Mi = Mo();
       const int hull_v0 = Mi->hull_start[is_body ? lt : nb], hull_v1 = Mi->hull_start[is_body ? lt + 1 : nb];
-      CgLds &G = *reinterpret_cast<CgLds *>(&W.u);
+      CgLds &G = PAIR ? *reinterpret_cast<CgLds *>(Gpair) : *reinterpret_cast<CgLds *>(&W.u);
       // ---- broad phase, one hull per lane
       const int nchunk = Mi->nchunk;
       const bool is_chunk = lt < nchunk;
       const int cbody = Mi->chunk_body[bl], cv0 = Mi->chunk_v0[bl], cv1 = is_chunk ? Mi->chunk_v1[bl] : 0;
       float Rz[3], zbc;
       {
-        const float zb = pos[2] + r[2] - floor_z;    // body origin above the floor (body lanes)
+        const float zb = posz + r[2] - floor_z;    // body origin above the floor (body lanes)
 #pragma unroll
         for (int c = 0; c < 3; c++) Rz[c] = wshfl(R[6 + c], cbody);
         zbc = wshfl(zb, cbody);
@@ -771,10 +857,10 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
       if (near_mask != 0u) {   // (an env with no hull near the floor - every second one under random actions - is done here)
       // clear the masks and the minima
       {
-        unsigned *z = &G.cm[0][0];
+        unsigned *z = &G.cm[0];
 #pragma unroll
-        for (int i = 0; i < (TL * CG_WORDS + 63) / 64; i++)
-          if (lt + 64 * i < TL * CG_WORDS) z[lt + 64 * i] = 0u;
+        for (int i = 0; i < (CG_WORDS + 63) / 64; i++)
+          if (lt + 64 * i < CG_WORDS) z[lt + 64 * i] = 0u;
         if (lt < TL) {   // (the all-ones key made here, not hoisted out of the substep loop as a register pair)
           int ones = -1;
           asm volatile("" : "+v"(ones));
@@ -793,11 +879,12 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
         if (near) {
           const int e = __popc(near_mask & ((1u << bl) - 1u));
           G.ent[e][0] = make_float4(__int_as_float(my_off + (cv1 - cv0)), __int_as_float(cv0 - my_off),
-                                    __int_as_float(cbody), __int_as_float(Mi->hull_start[cbody]));
+                                    __int_as_float(cbody | (Mi->cm_pack[cbody] << 8)), __int_as_float(Mi->hull_start[cbody]));
+          // (.z: body in bits 0..7, its mask's log2 period in 8..15, its first mask word from bit 16)
           G.ent[e][1] = make_float4(Rz[0], Rz[1], Rz[2], zbc);
         }
       }
-      __syncthreads();
+      WSYNC();
       SUBSTAMP(9);    // broad phase + table
       // ---- the scan
       if (total > 0) {
@@ -806,14 +893,16 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
         constexpr int UN = 4;
         for (int f0 = 0; f0 < total; f0 += 64 * UN) {
           float4 h[UN], q[UN];
-          int vtx[UN], rel[UN], bod[UN];
+          int vtx[UN], rel[UN], bod[UN], mlg[UN], mof[UN];
 #pragma unroll
           for (int u = 0; u < UN; u++) {
             const int f = f0 + 64 * u + lt;
             // advance the cursor to the hull that holds list position f (hulls hold >= 1 vertex: a few steps at most)
             while (f < total && f >= __float_as_int(e0.x)) { cur++; e0 = G.ent[cur][0]; e1 = G.ent[cur][1]; }
             vtx[u] = f < total ? f + __float_as_int(e0.y) : -1;
-            bod[u] = __float_as_int(e0.z);
+            bod[u] = __float_as_int(e0.z) & 255;
+            mlg[u] = (__float_as_int(e0.z) >> 8) & 255;
+            mof[u] = __float_as_int(e0.z) >> 16;
             rel[u] = vtx[u] - __float_as_int(e0.w);
             q[u] = e1;
             h[u] = args.arr.hull[vtx[u] < 0 ? 0 : vtx[u]];
@@ -823,7 +912,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
             // only the height decides; h.w = support radius (0 for a hull vertex): the sphere's lowest point
             const float dd = q[u].w + (q[u].x * h[u].x + q[u].y * h[u].y + q[u].z * h[u].z) - h[u].w;
             if (vtx[u] >= 0 && dd < margin) {
-              if (rel[u] < 32 * CG_WORDS) atomicOr(&G.cm[bod[u]][rel[u] & 31], 1u << (rel[u] >> 5));
+              if (mlg[u] != 0 && rel[u] < (32 << mlg[u])) atomicOr(&G.cm[mof[u] + (rel[u] & ((1 << mlg[u]) - 1))], 1u << (rel[u] >> mlg[u]));
               unsigned ub = __float_as_uint(dd);
               ub ^= (ub >> 31) ? 0xffffffffu : 0x80000000u;    // order-preserving map of the float to unsigned
               atomicMin(&G.best[bod[u]], ((unsigned long long)ub << 32) | (unsigned)vtx[u]);
@@ -831,7 +920,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
           }
         }
       }
-      __syncthreads();
+      WSYNC();
       SUBSTAMP(10);   // scan
       // ---- per body: its deepest vertex
       unsigned active_mask = 0u;
@@ -846,7 +935,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
           float w[3];
           matvec3(R, hv, w);
           a_x[0] = r[0] + w[0]; a_x[1] = r[1] + w[1]; a_x[2] = r[2] + w[2] - hw.w;
-          a_d = pos[2] + a_x[2] - floor_z;
+          a_d = posz + a_x[2] - floor_z;
         }
         active_mask = (unsigned)__ballot(a_v >= 0);
       }
@@ -870,7 +959,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
         const bool mine = lt < 32 && ((active_mask >> bl) & 1u);
         const int slot = __popc(active_mask & ((1u << bl) - 1u));
         if (mine) {
-          float *o = W.cpt[slot];
+          float *o = E.cpt[slot];
           o[0] = __int_as_float(lt); o[1] = a_x[0]; o[2] = a_x[1]; o[3] = a_x[2]; o[4] = a_d;
         }
         nc = n_active;
@@ -896,17 +985,25 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
         for (int c = 0; c < 3; c++) { rb[c] = wshfl(r[c], b); px[0][c] = wshfl(a_x[c], b); }
         sel[0] = act ? wshfl(a_v, b) : -1;
         const int v0 = wshfl(hull_v0, b), v1 = wshfl(hull_v1, b);
-        const bool masked = (v1 - v0) <= 32 * CG_WORDS;
-        // this lane's candidate words (masked bodies); a body beyond the mask capacity is swept
+        const int cmp = Mi->cm_pack[b & (TL - 1)], mlog = cmp & 255;
+        const bool masked = mlog != 0;
+        // this lane's candidate words (masked bodies); a body without a mask is swept. Lane g of a group owns a FIXED subset
+        // of the body's vertices - which one does not matter (the passes pick by score, ties by vertex index):
+        //   period 32: the vertices congruent to g modulo the group size (words g, g + GS, ...; GS = 64: every other bit);
+        //   period 8:  word g & 7, and of its bits those congruent to g >> 3 modulo GS / 8 - ONE word per lane
         unsigned m0 = 0u, m1 = 0u, m2 = 0u, m3 = 0u;
         if (act && masked) {
-          const unsigned *cw = G.cm[b];
-          if (GS >= 64) m0 = cw[g & 31] & ((g >> 5) ? 0xAAAAAAAAu : 0x55555555u);
+          const unsigned *cw = G.cm + (cmp >> 8);
+          if (mlog == 3) {
+            const unsigned pick = GS >= 64 ? 0x01010101u : (GS >= 32 ? 0x11111111u : (GS >= 16 ? 0x55555555u : 0xFFFFFFFFu));
+            m0 = cw[g & 7] & (pick << (g >> 3));
+          } else if (GS >= 64) m0 = cw[g & 31] & ((g >> 5) ? 0xAAAAAAAAu : 0x55555555u);
           else if (GS >= 32) m0 = cw[g];
           else if (GS >= 16) { m0 = cw[g]; m1 = cw[g + 16]; }
           else { m0 = cw[g]; m1 = cw[g + 8]; m2 = cw[g + 16]; m3 = cw[g + 24]; }
         }
-        const int wstep = GS >= 32 ? 0 : GS;
+        const int wstep = (mlog == 3 || GS >= 32) ? 0 : GS;
+        const int vmul = mlog == 3 ? 8 : 32, wb0 = mlog == 3 ? (g & 7) : (g & 31);   // bit j of the word at base wb: vertex v0 + vmul j + wb
         int nsel = act ? 1 : 0;
         bool stop = !act;
         // A lane with at most CC in-margin vertices (every lane of a body of toe size) loads and places them ONCE and
@@ -921,14 +1018,14 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
         for (int u = 0; u < CC; u++) { cvx[u] = -1; cx[u][0] = cx[u][1] = cx[u][2] = 0.f; }
         if (cached) {
           unsigned c0 = m0, c1 = m1, c2 = m2, c3 = m3;
-          int wb = g & 31;
+          int wb = wb0;
           float4 hc[CC];
 #pragma unroll
           for (int u = 0; u < CC; u++) {
             if (c0 == 0u) { c0 = c1; c1 = c2; c2 = c3; c3 = 0u; wb += wstep; }   // next word of this lane
             const int j = c0 != 0u ? (__ffs(c0) - 1) : -1;
             c0 &= c0 - 1u;            // (0 stays 0)
-            cvx[u] = j >= 0 ? v0 + 32 * j + wb : -1;
+            cvx[u] = j >= 0 ? v0 + vmul * j + wb : -1;
             hc[u] = args.arr.hull[cvx[u] >= 0 ? cvx[u] : v0];
           }
 #pragma unroll
@@ -937,7 +1034,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
             float w[3];
             matvec3(Rb, hv, w);
             cx[u][0] = rb[0] + w[0]; cx[u][1] = rb[1] + w[1]; cx[u][2] = rb[2] + w[2] - hc[u].w;
-            const float dd = pos[2] + cx[u][2] - floor_z;
+            const float dd = posz + cx[u][2] - floor_z;
             if (!(dd < margin)) cvx[u] = -1;
           }
         }
@@ -958,7 +1055,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
             float w[3];
             matvec3(Rb, hv, w);
             const float x0 = rb[0] + w[0], x1 = rb[1] + w[1], x2 = rb[2] + w[2] - h.w;
-            const float dd = pos[2] + x2 - floor_z;
+            const float dd = posz + x2 - floor_z;
             if (!(dd < margin)) return;
             if (v == sel[0] || v == sel[1] || v == sel[2]) return;
             const float dx = x0 - px[0][0], dy = x1 - px[0][1];
@@ -986,7 +1083,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
             }
           } else if (__ballot(act && !masked) == 0ull) {
             unsigned c0 = stop ? 0u : m0, c1 = stop ? 0u : m1, c2 = stop ? 0u : m2, c3 = stop ? 0u : m3;
-            int wb = g & 31;
+            int wb = wb0;
             constexpr int UC = 2;   // candidates per trip: their loads are issued together
             while (__ballot((c0 | c1 | c2 | c3) != 0u) != 0ull) {
               int vi[UC];
@@ -996,7 +1093,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
                 if (c0 == 0u) { c0 = c1; c1 = c2; c2 = c3; c3 = 0u; wb += wstep; }   // next word of this lane
                 const int j = c0 != 0u ? (__ffs(c0) - 1) : -1;
                 c0 &= c0 - 1u;            // (0 stays 0)
-                vi[u] = j >= 0 ? v0 + 32 * j + wb : -1;
+                vi[u] = j >= 0 ? v0 + vmul * j + wb : -1;
                 hc[u] = args.arr.hull[vi[u] >= 0 ? vi[u] : v0];
               }
 #pragma unroll
@@ -1037,8 +1134,8 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             if (k < nsel && off + k < maxc) {
-              float *o = W.cpt[off + k];
-              o[0] = __int_as_float(b); o[1] = px[k][0]; o[2] = px[k][1]; o[3] = px[k][2]; o[4] = pos[2] + px[k][2] - floor_z;
+              float *o = E.cpt[off + k];
+              o[0] = __int_as_float(b); o[1] = px[k][0]; o[2] = px[k][1]; o[3] = px[k][2]; o[4] = posz + px[k][2] - floor_z;
             }
           }
         }
@@ -1047,11 +1144,23 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
       }   // near_mask != 0
     }
     nc = uni(nc);
+    if (PAIR) { if (lane_id() == 0) E.xch[35] = __int_as_float(nc); }
+    }   // e
+    }   // contact generation (PAIR: wave 1)
     STAMP(1);
+    if (!PAIR) {
     RELANE();
     RETREE();
     REAXIS();
+    }
 
+    Chol6 I0c;
+    float a0[6];
+    float nw[3], nv[3];
+#ifndef TREX_GENERIC_TREE
+#define TREX_GENERIC_TREE 0      // diagnostic: the single-env launch through the two-env form of the tree phases (with one half)
+#endif
+    if (!PAIR && !TREX_GENERIC_TREE) {
     // ================================================================ tree dynamics
     // ---- rigid-body spatial inertia about the body origin, bias force (both straight to the body's LDS slot:
     // the tip-to-base pass works on LDS-resident inertias), velocity-product acceleration cv (registers)
@@ -1156,20 +1265,20 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
         }
       }
       if (is_body) {
-        float *o = W.u.aba[bl];
+        float *o = W.u.t.aba[bl];
 #pragma unroll
         for (int k = 0; k < 6; k++) { o[k] = IA.A[k]; o[15 + k] = IA.C[k]; o[21 + k] = pA[k]; }
 #pragma unroll
         for (int k = 0; k < 9; k++) o[6 + k] = IA.B[k];
       }
     }
-    __syncthreads();
+    WSYNC();
     STAMP(2);
     RELANE();
     RETREE();
     REAXIS();
 
-    // ---- ABA pass 2 (tip to base) on LDS-resident inertias: slot b of W.u.aba holds body b's rigid-body inertia
+    // ---- ABA pass 2 (tip to base) on LDS-resident inertias: slot b of W.u.t.aba holds body b's rigid-body inertia
     // (21) and bias force (6) about its own origin. Level by level, the lanes AT depth d take their slot, add
     // what their children left in theirs (already shifted to this body's origin; fixed order), form U, 1/D, u
     // (which go to the body record: pass 3 and the row walks read them there), remove the joint's freedom,
@@ -1180,13 +1289,13 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
       const float tau_j = -Mi->damp[bl] * W.st[ST_QD][bl];  // explicit joint damping torque
       for (int d = maxdepth; d >= 0; d--) {
         if (depth == d) {
-          float *o = W.u.aba[bl];
+          float *o = W.u.t.aba[bl];
           const unsigned ch4 = __float_as_uint(reinterpret_cast<const float *>(&W.body[BREC * bl + 4])[3]);
           float acc[27];
           {
             // own slot and first child's in flight together (most bodies have exactly one child)
             const int c0 = (int)(ch4 & 255u);
-            const float *c = W.u.aba[c0 == 255 ? bl : c0];
+            const float *c = W.u.t.aba[c0 == 255 ? bl : c0];
             const float w0 = c0 == 255 ? 0.f : 1.f;
 #pragma unroll
             for (int k = 0; k < 27; k++) acc[k] = __builtin_fmaf(w0, c[k], o[k]);
@@ -1195,7 +1304,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
           for (int kc = 1; kc < MAXCH; kc++) {   // further children, fixed order (packed without gaps)
             const int ch = (int)((ch4 >> (8 * kc)) & 255u);
             if (ch == 255) break;
-            const float *c = W.u.aba[ch];
+            const float *c = W.u.t.aba[ch];
 #pragma unroll
             for (int k = 0; k < 27; k++) acc[k] += c[k];
           }
@@ -1270,7 +1379,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
             for (int k = 0; k < 9; k++) o[6 + k] = IA.B[k];
           }
         }
-        __syncthreads();
+        WSYNC();
       }
       if (lt < TL && !is_joint) {   // base and unused lanes: inert records
         float4 *rec = &W.body[BREC * lt];
@@ -1285,10 +1394,8 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
     REAXIS();
 
     // ---- floating base: a0 = -(IA_0)^-1 pA_0; the Cholesky factor of IA_0 is wave-uniform (SGPRs)
-    Chol6 I0c;
-    float a0[6];
     {
-      const float *o = W.u.aba[0];   // every lane reads the same words: LDS broadcast
+      const float *o = W.u.t.aba[0];   // every lane reads the same words: LDS broadcast
       Sym6 I0;
 #pragma unroll
       for (int k = 0; k < 6; k++) { I0.A[k] = o[k]; I0.C[k] = o[15 + k]; }
@@ -1337,7 +1444,6 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
       }
     }
     // ---- unconstrained velocity update
-    float nw[3], nv[3];
     {
       const float vmax = M->prm[TP_MAX_COORD_VEL];
       float wxv[3];
@@ -1364,7 +1470,340 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
         }
       }
     }
-    __syncthreads();
+    } else {
+      if (wave == 0) {
+        // ... which runs the lane-per-body phases for BOTH: H = the LDS of the lane's half, hoff = its first lane
+        WaveLds *H;
+        int hoff;
+#define RELANE2() do { lt = lane_id(); bl = lt & (TL - 1); hoff = PAIR ? (lt & TL) : 0; H = &Wpair[PAIR ? (lt >> 5) : 0];            \
+                       is_body = (PAIR ? bl : lt) < nb; is_joint = (PAIR ? bl : lt) >= 1 && (PAIR ? bl : lt) < nb; } while (0)
+#define REAXIS2() do { const float4 q0_ = H->body[BREC * bl], q4_ = H->body[BREC * bl + 4];                          \
+                       Sa[0] = is_joint ? q0_.x : 0.f; Sa[1] = is_joint ? q0_.y : 0.f; Sa[2] = is_joint ? q0_.z : 0.f; \
+                       dpar[0] = q4_.x; dpar[1] = q4_.y; dpar[2] = q4_.z; } while (0)
+#define RETREE2() do { const int lk_ = __float_as_int(reinterpret_cast<const float *>(&H->body[BREC * bl + 3])[2]); \
+                       psrc = lk_ & 255; depth = is_body ? (lk_ >> 8) : -1; } while (0)
+        RELANE2();
+        RETREE2();
+        REAXIS2();
+    // ================================================================ tree dynamics
+    // ---- rigid-body spatial inertia about the body origin, bias force (both straight to the body's LDS slot:
+    // the tip-to-base pass works on LDS-resident inertias), velocity-product acceleration cv (registers)
+    float cv[6];
+    {
+      Sym6 IA;
+      float pA[6];
+      const float qd = H->st[ST_QD][bl];
+      // spatial velocity of every body ABOUT ITS OWN ORIGIN for the base twist and the joint rates
+      float vel[6];
+#pragma unroll
+      for (int c = 0; c < 3; c++) { vel[c] = H->xch[c]; vel[3 + c] = H->xch[3 + c]; }
+      for (int d = 1; d <= maxdepth; d++) {
+        float pv[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) pv[c] = wshfl(vel[c], psrc + hoff);
+        if (depth == d) {
+          float wxd[3];
+          cross3(pv, dpar, wxd);   // velocity of the parent-body point at this body's origin
+#pragma unroll
+          for (int c = 0; c < 3; c++) { vel[c] = pv[c] + Sa[c] * qd; vel[3 + c] = pv[3 + c] + wxd[c]; }
+        }
+      }
+      float Rh[9];
+#pragma unroll
+      for (int c = 0; c < 9; c++) Rh[c] = H->u.t.rtab[bl][c];
+      const TrexDeviceModel *Mi = Mo();
+      float comb[3], inb[6];
+      const float mscale = args.arr.domain ? args.arr.mass_scale[(size_t)__float_as_int(H->xch[6]) * TL + bl] : 1.0f;
+      const float mass = Mi->mass[bl] * mscale;
+#pragma unroll
+      for (int c = 0; c < 3; c++) comb[c] = Mi->com[c][bl];
+#pragma unroll
+      for (int c = 0; c < 6; c++) inb[c] = Mi->inertia[c][bl];
+      const float grav = Mi->prm[TP_GRAVITY], kdamp = Mi->prm[TP_LINK_DAMPING];
+      float comw[3], Icw[6];   // comw = COM offset from the body origin, world axes
+      {
+        matvec3(Rh, comb, comw);
+        // Ic_world = R Ib R^T (symmetric)
+        float t[9];
+        const float Ib[9] = {inb[0], inb[1], inb[2], inb[1], inb[3], inb[4], inb[2], inb[4], inb[5]};
+        matmul3(Rh, Ib, t);
+        const int ia[6] = {0, 0, 0, 1, 1, 2}, ib[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+          Icw[k] = mscale * (t[3 * ia[k]] * Rh[3 * ib[k]] + t[3 * ia[k] + 1] * Rh[3 * ib[k] + 1] + t[3 * ia[k] + 2] * Rh[3 * ib[k] + 2]);
+      }
+      {
+        const float cc = dot3(comw, comw);
+        IA.A[0] = Icw[0] + mass * (cc - comw[0] * comw[0]);
+        IA.A[1] = Icw[1] - mass * comw[0] * comw[1];
+        IA.A[2] = Icw[2] - mass * comw[0] * comw[2];
+        IA.A[3] = Icw[3] + mass * (cc - comw[1] * comw[1]);
+        IA.A[4] = Icw[4] - mass * comw[1] * comw[2];
+        IA.A[5] = Icw[5] + mass * (cc - comw[2] * comw[2]);
+        // B = m * [c]x
+        IA.B[0] = 0.f;              IA.B[1] = -mass * comw[2];  IA.B[2] = mass * comw[1];
+        IA.B[3] = mass * comw[2];   IA.B[4] = 0.f;              IA.B[5] = -mass * comw[0];
+        IA.B[6] = -mass * comw[1];  IA.B[7] = mass * comw[0];   IA.B[8] = 0.f;
+        IA.C[0] = mass; IA.C[1] = 0.f; IA.C[2] = 0.f; IA.C[3] = mass; IA.C[4] = 0.f; IA.C[5] = mass;
+      }
+      if (!is_body) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) { IA.A[k] = (k == 0 || k == 3 || k == 5) ? 1.f : 0.f; IA.C[k] = IA.A[k]; }
+#pragma unroll
+        for (int k = 0; k < 9; k++) IA.B[k] = 0.f;
+      }
+      {
+        float h[6];
+        sym6_mul(IA, vel, h);
+        // v x* h
+        float a[3], b[3], c[3];
+        cross3(vel, h, a); cross3(vel + 3, h + 3, b); cross3(vel, h + 3, c);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { pA[k] = a[k] + b[k]; pA[3 + k] = c[k]; }
+        float f[3] = {0.f, 0.f, -mass * grav}, n[3] = {0.f, 0.f, 0.f};
+        if (kdamp > 0.f) {
+          float vc[3], wxc[3], Iw[3];
+          cross3(vel, comw, wxc);
+#pragma unroll
+          for (int k = 0; k < 3; k++) vc[k] = vel[3 + k] + wxc[k];
+          const float sv = sqrtf(dot3(vc, vc)), sw = sqrtf(dot3(vel, vel));
+          sym3_mul(Icw, vel, Iw);
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            f[k] -= mass * vc[k] * (kdamp + kdamp * sv);
+            n[k] -= Iw[k] * (kdamp + kdamp * sw);
+          }
+        }
+        float cxf[3];
+        cross3(comw, f, cxf);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { pA[k] -= n[k] + cxf[k]; pA[3 + k] -= f[k]; }
+        // c = vel x (S qd), S = [Sa; 0]
+        float sq[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) sq[k] = Sa[k] * qd;
+        float x0[3], x2[3];
+        cross3(vel, sq, x0); cross3(vel + 3, sq, x2);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { cv[k] = x0[k]; cv[3 + k] = x2[k]; }
+        if (!is_body) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) { pA[k] = 0.f; cv[k] = 0.f; }
+        }
+      }
+      if (is_body) {
+        float *o = H->u.t.aba[bl];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { o[k] = IA.A[k]; o[15 + k] = IA.C[k]; o[21 + k] = pA[k]; }
+#pragma unroll
+        for (int k = 0; k < 9; k++) o[6 + k] = IA.B[k];
+      }
+    }
+    WSYNC();
+    RELANE2();
+    RETREE2();
+    REAXIS2();
+
+    // ---- ABA pass 2 (tip to base) on LDS-resident inertias: slot b of H->u.t.aba holds body b's rigid-body inertia
+    // (21) and bias force (6) about its own origin. Level by level, the lanes AT depth d take their slot, add
+    // what their children left in theirs (already shifted to this body's origin; fixed order), form U, 1/D, u
+    // (which go to the body record: pass 3 and the row walks read them there), remove the joint's freedom,
+    // shift to the parent's origin and put the result back for the parent. One LDS round trip and one barrier
+    // per level; nothing of this is carried in registers between levels. Level 0 is the base: it only sums.
+    {
+      const TrexDeviceModel *Mi = Mo();
+      const float tau_j = -Mi->damp[bl] * H->st[ST_QD][bl];  // explicit joint damping torque
+      for (int d = maxdepth; d >= 0; d--) {
+        if (depth == d) {
+          float *o = H->u.t.aba[bl];
+          const unsigned ch4 = __float_as_uint(reinterpret_cast<const float *>(&H->body[BREC * bl + 4])[3]);
+          float acc[27];
+          {
+            // own slot and first child's in flight together (most bodies have exactly one child)
+            const int c0 = (int)(ch4 & 255u);
+            const float *c = H->u.t.aba[c0 == 255 ? bl : c0];
+            const float w0 = c0 == 255 ? 0.f : 1.f;
+#pragma unroll
+            for (int k = 0; k < 27; k++) acc[k] = __builtin_fmaf(w0, c[k], o[k]);
+          }
+#pragma unroll 1
+          for (int kc = 1; kc < MAXCH; kc++) {   // further children, fixed order (packed without gaps)
+            const int ch = (int)((ch4 >> (8 * kc)) & 255u);
+            if (ch == 255) break;
+            const float *c = H->u.t.aba[ch];
+#pragma unroll
+            for (int k = 0; k < 27; k++) acc[k] += c[k];
+          }
+          if (d == 0) {
+#pragma unroll
+            for (int k = 0; k < 27; k++) o[k] = acc[k];
+          } else {
+            Sym6 IA;
+            float pA[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) { IA.A[k] = acc[k]; IA.C[k] = acc[15 + k]; pA[k] = acc[21 + k]; }
+#pragma unroll
+            for (int k = 0; k < 9; k++) IA.B[k] = acc[6 + k];
+            float U[6];   // U = IA S, S = [Sa; 0]
+            sym3_mul(IA.A, Sa, U);
+            U[3] = IA.B[0] * Sa[0] + IA.B[3] * Sa[1] + IA.B[6] * Sa[2];
+            U[4] = IA.B[1] * Sa[0] + IA.B[4] * Sa[1] + IA.B[7] * Sa[2];
+            U[5] = IA.B[2] * Sa[0] + IA.B[5] * Sa[1] + IA.B[8] * Sa[2];
+            const float D = dot3(Sa, U);
+            const float rD = __builtin_amdgcn_rcpf(D);
+#if TREX_ABLATE_EXACT_MATH
+            const float invD = 1.0f / D;
+#else
+            const float invD = rD * __builtin_fmaf(-D, rD, 2.0f);   // v_rcp_f32 + one Newton step (no IEEE division expansion)
+#endif
+            const float u = tau_j - dot3(Sa, pA);
+            float Ud[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) Ud[k] = U[k] * invD;
+            {
+              float4 *rec = &H->body[BREC * bl];
+              rec[0] = make_float4(Sa[0], Sa[1], Sa[2], invD);
+              rec[2] = make_float4(Ud[0], Ud[1], Ud[2], Ud[3]);
+              rec[3] = make_float4(Ud[4], Ud[5], __int_as_float(psrc + 256 * depth), u * invD);
+            }
+            {   // pa = pA + Ia c + U u / D with Ia c = IA c - U (U.c) / D
+              float Ic[6];
+              sym6_mul(IA, cv, Ic);
+              const float coef = (u - dot6(U, cv)) * invD;
+#pragma unroll
+              for (int k = 0; k < 6; k++) pA[k] += Ic[k] + U[k] * coef;
+            }
+            sym6_rank1_sub(IA, U, Ud);
+            // shift both to the parent's origin (this origin = parent origin + d, d = dpar):
+            //   n' = n + d x f,  B' = B + [d]x C,  A' = A + X^T + X', X = [d]x B^T, X' = [d]x B'^T
+            {
+              cross3_acc(dpar, pA + 3, pA[0], pA[1], pA[2]);
+              const int sidx[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+#pragma unroll
+              for (int i = 0; i < 3; i++) {   // A_ij += X_ji = (d x row i of B)_j, j >= i
+                float t[3] = {0.f, 0.f, 0.f};
+                if (i == 0) cross3_acc(dpar, IA.B, IA.A[0], IA.A[1], IA.A[2]);
+                else if (i == 1) cross3_acc(dpar, IA.B + 3, t[0], IA.A[3], IA.A[4]);
+                else cross3_acc(dpar, IA.B + 6, t[0], t[1], IA.A[5]);
+              }
+#pragma unroll
+              for (int j = 0; j < 3; j++) {   // column j of [d]x C = d x (column j of C)
+                const float cj[3] = {IA.C[sidx[0][j]], IA.C[sidx[1][j]], IA.C[sidx[2][j]]};
+                cross3_acc(dpar, cj, IA.B[j], IA.B[3 + j], IA.B[6 + j]);
+              }
+#pragma unroll
+              for (int j = 0; j < 3; j++) {   // A_ij += X'_ij = (d x row j of B')_i, i <= j
+                float t[3] = {0.f, 0.f, 0.f};
+                if (j == 0) cross3_acc(dpar, IA.B, IA.A[0], t[1], t[2]);
+                else if (j == 1) cross3_acc(dpar, IA.B + 3, IA.A[1], IA.A[3], t[2]);
+                else cross3_acc(dpar, IA.B + 6, IA.A[2], IA.A[4], IA.A[5]);
+              }
+            }
+#pragma unroll
+            for (int k = 0; k < 6; k++) { o[k] = IA.A[k]; o[15 + k] = IA.C[k]; o[21 + k] = pA[k]; }
+#pragma unroll
+            for (int k = 0; k < 9; k++) o[6 + k] = IA.B[k];
+          }
+        }
+        WSYNC();
+      }
+      if ((PAIR || lt < TL) && !is_joint) {   // base and unused lanes: inert records
+        float4 *rec = &H->body[BREC * bl];
+        rec[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rec[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rec[3] = make_float4(0.f, 0.f, __int_as_float(psrc + 256 * (depth < 0 ? 255 : depth)), 0.f);
+      }
+    }
+    RELANE2();
+    RETREE2();
+    REAXIS2();
+
+    // ---- floating base: a0 = -(IA_0)^-1 pA_0; every lane of a half factors its env's matrix (the same arithmetic on the
+    // same words); lane 0 of the half hands the factor and a0 to the env's own wave
+    float a0h[6];
+    {
+      const float *o = H->u.t.aba[0];
+      Sym6 I0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) { I0.A[k] = o[k]; I0.C[k] = o[15 + k]; }
+#pragma unroll
+      for (int k = 0; k < 9; k++) I0.B[k] = o[6 + k];
+      float p0[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) p0[k] = -o[21 + k];
+      float full[36];
+      sym6_full(I0, full);
+      Chol6 c;
+      chol6_factor(full, c);
+      chol6_solve(c, p0, a0h);
+      if (bl == 0) {
+        float *x = H->xch + 8;
+#pragma unroll
+        for (int k = 0; k < 15; k++) x[k] = c.l[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { x[15 + k] = c.il[k]; x[21 + k] = a0h[k]; }
+      }
+    }
+    // ---- ABA pass 3 (base to tip): accelerations; qdd = (u - U.a) / D = u/D - (U/D).a from the body record
+    float qdd = 0.f;
+    {
+      const float4 q2 = H->body[BREC * bl + 2], q3 = H->body[BREC * bl + 3];
+      const float Ud[6] = {q2.x, q2.y, q2.z, q2.w, q3.x, q3.y};
+      float acc[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) acc[k] = a0h[k];
+      for (int d = 1; d <= maxdepth; d++) {
+        float pa[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) pa[k] = wshfl(acc[k], psrc + hoff);
+        if (depth == d) {
+          float axd[3];
+          cross3(pa, dpar, axd);   // parent acceleration seen at this body's origin
+#pragma unroll
+          for (int k = 0; k < 3; k++) pa[3 + k] += axd[k];
+#pragma unroll
+          for (int k = 0; k < 6; k++) pa[k] += cv[k];
+          qdd = q3.w - dot6(Ud, pa);
+#pragma unroll
+          for (int k = 0; k < 3; k++) acc[k] = pa[k] + Sa[k] * qdd;
+#pragma unroll
+          for (int k = 3; k < 6; k++) acc[k] = pa[k];
+        }
+      }
+    }
+    // ---- unconstrained joint rates of both envs (each wave forms its own base twist below)
+    {
+      const float vmax = M->prm[TP_MAX_COORD_VEL];
+      const float nqd = is_joint ? fminf(fmaxf(H->st[ST_QD][bl] + qdd * dt, -vmax), vmax) : 0.f;
+      if (PAIR || lt < TL) {
+        reinterpret_cast<float *>(&H->body[BREC * bl + 1])[3] = nqd;
+        H->st[ST_NQD][bl] = nqd;
+      }
+    }
+#undef RELANE2
+#undef REAXIS2
+#undef RETREE2
+      }
+      if (PAIR) __syncthreads(); else WSYNC();      // records (U/D, 1/D, u/D, updated rates), base factor and base acceleration are in LDS
+      if (act) {
+        nc = uni(__float_as_int(W.xch[35]));
+        const float *x = W.xch + 8;      // (every lane reads the same words: LDS broadcast)
+#pragma unroll
+        for (int k = 0; k < 15; k++) I0c.l[k] = uni(x[k]);
+#pragma unroll
+        for (int k = 0; k < 6; k++) { I0c.il[k] = uni(x[15 + k]); a0[k] = uni(x[21 + k]); }
+        const float vmax = M->prm[TP_MAX_COORD_VEL];
+        float wxv[3];
+        cross3(bw, bv, wxv);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          nw[k] = uni(fminf(fmaxf(bw[k] + a0[k] * dt, -vmax), vmax));
+          nv[k] = uni(fminf(fmaxf(bv[k] + (a0[3 + k] + wxv[k]) * dt, -vmax), vmax));
+        }
+      }
+    }
+    if (act) {
+    WSYNC();
     STAMP(4);
     RELANE();
 
@@ -1482,7 +1921,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
       }
     }
     const unsigned lim_mask = (unsigned)__ballot(ldir != 0.f);
-    __syncthreads();   // the body records are dead: the z0 stash may overwrite them; so are the inertia slots
+    WSYNC();   // the body records are dead: the z0 stash may overwrite them; so are the inertia slots
     {
       float *zs = reinterpret_cast<float *>(W.body);
 #pragma unroll
@@ -1494,7 +1933,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
       dc[2] = make_float4(z00[1], z00[2], z00[3], z00[4]);
       dc[3] = make_float4(z00[5], 0.f, 0.f, 0.f);
     }
-    __syncthreads();
+    WSYNC();
     STAMP(5);
     RELANE();
 
@@ -1969,7 +2408,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
         }
       }
     }
-    __syncthreads();
+    WSYNC();
 
     // ---- commit velocities, integrate positions
     if (lt < TL) {
@@ -2008,8 +2447,9 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
     }
     stat_nc = nc;
     stat_imp = nimp;
-    __syncthreads();
+    WSYNC();
     STAMP(8);
+    }   // act (rows, sweeps, integration)
 #undef RELANE
 #undef RETREE
 #undef REAXIS
@@ -2107,6 +2547,8 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
 
 template <bool RESET, bool DEBUG>
 __global__ __launch_bounds__(64, 4) void trex_step_kernel(KernelArgs args) { trex_step_body<RESET, DEBUG, false>(args, (int)blockIdx.x); }
+// two envs per workgroup with split roles between the barriers of a substep (PAIR above): even batches of at most 4096 envs
+__global__ __launch_bounds__(128, 4) void trex_step_pair_kernel(KernelArgs args) { trex_step_body<false, false, false, true>(args, (int)blockIdx.x); }
 // S env-steps per launch (trex_batch_step_many)
 __global__ __launch_bounds__(64, 4) void trex_step_many_kernel(KernelArgs args) { trex_step_body<false, false, true>(args, (int)blockIdx.x); }
 
@@ -2290,6 +2732,7 @@ hipError_t trex_launch_step(const TrexDeviceModel *model, TrexBatchArrays arr, i
   hipLaunchKernelGGL((trex_step_kernel<false, false>), dim3(n), dim3(64), 0, stream, a);
 #else
   if (debug) hipLaunchKernelGGL((trex_step_kernel<false, true>), dim3(n), dim3(64), 0, stream, a);
+  else if (TREX_PAIR_LAUNCH && (n & 1) == 0 && n <= 4096) hipLaunchKernelGGL(trex_step_pair_kernel, dim3(n / 2), dim3(128), 0, stream, a);
   else hipLaunchKernelGGL((trex_step_kernel<false, false>), dim3(n), dim3(64), 0, stream, a);
 #endif
   return hipGetLastError();
@@ -2358,7 +2801,9 @@ hipError_t trex_launch_copy_mass_scale(const float *src, float *dst, int n, int 
   return hipGetLastError();
 }
 
-int trex_step_lds_bytes(void) { return (int)sizeof(WaveLds); }
-int trex_step_envs_per_workgroup(void) { return 1; }
+// launch shape of the step launch for a batch of n envs (trex_batch_launch_info): two envs per workgroup - the pair form - for an
+// even batch that is resident at once, one otherwise
+int trex_step_envs_per_workgroup(int n) { return (TREX_PAIR_LAUNCH && (n & 1) == 0 && n <= 4096) ? 2 : 1; }
+int trex_step_lds_bytes(int n) { return trex_step_envs_per_workgroup(n) == 2 ? (int)(2 * sizeof(WaveLds) + sizeof(CgLds)) : (int)sizeof(WaveLds); }
 
 }  // extern "C"
