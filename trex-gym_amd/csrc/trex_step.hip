@@ -441,6 +441,8 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
       // SIMD pair: pair indices go to them like ranks go to single-env workgroups - first block in order, later blocks reversed.
       const int bq = wg_in >> 9, half = args.n_envs >> 1, bm = min(512, half - (bq << 9));
       const int pidx = bq == 0 ? wg_in : (bq << 9) + (bm - 1 - (wg_in & 511));
+      // (measured, 4096 envs: this deal 11.69 M; heaviest with the median env 11.55 M; workgroups in plain rank order 11.67 M; the
+      // light env's wave running the tree dynamics and the heavy one the contacts 11.58 M)
       r = wave == 0 ? pidx : args.n_envs - 1 - pidx;
     }
     // (not better, measured: SIMD j taking rank j and the 3 LIGHTEST envs still to be dealt - 11.07 M against 11.13 M
@@ -579,8 +581,11 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
 #define TREX_TREE_HEAVY 12
 #endif
   int prio_nc = 0;      // contact points of the env's last substep (before the first one: of its last step)
+  // (PAIR: the heaviest envs' waves no longer generate their own contacts, and the top level for them outside the sweeps stopped
+  // paying - 11.71 M without it against 11.68 M; priorities BY ROLE were measured too: the tree-dynamics wave one level up 11.44 M,
+  // the contact wave one level up 11.65 M, the tree-dynamics wave at level 2 over the alternation 11.43 M; no priorities 10.07 M)
   auto set_tree_priority = [&](int substep) {   // outside the sweeps: the pairs take turns
-    if (TREX_TREE_HEAVY > 0 && prio_nc >= TREX_TREE_HEAVY) { __builtin_amdgcn_s_setprio(3); return; }
+    if (!PAIR && TREX_TREE_HEAVY > 0 && prio_nc >= TREX_TREE_HEAVY) { __builtin_amdgcn_s_setprio(3); return; }
     if (aged_launch && ((wave_pair + substep) & 1)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
   };
 #if TREX_PRIO_MODE == 1
