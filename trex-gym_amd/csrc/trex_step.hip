@@ -98,6 +98,15 @@ __device__ __forceinline__ int rl(int v, int src) { return __builtin_amdgcn_read
 __device__ __forceinline__ unsigned rl(unsigned v, int src) { return (unsigned)__builtin_amdgcn_readlane((int)v, src); }
 __device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// the same through an asm the optimiser cannot see through: a readfirstlane of a value it KNOWS to be uniform is folded away, and the
+// value then stays in the vector register that produced it
+// (with the wait states the hazard rules ask for and the compiler does not add around an asm: one between the VALU write of the
+// source and v_readfirstlane, two before a VALU may read the scalar result)
+__device__ __forceinline__ float uni_sgpr(float v) {
+  float r;
+  asm volatile("s_nop 0\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 1" : "=s"(r) : "v"(v));
+  return r;
+}
 // all-reduce over the 64 lanes on the VALU (no LDS round trips): four DPP steps inside the 16-lane rows,
 // then gfx950's v_permlane16_swap (rows 0<->1, 2<->3) and v_permlane32_swap (halves).
 template <int CTRL>
@@ -469,8 +478,11 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
   env = uni(env);
 
   const int nb = M->nb, maxdepth = M->maxdepth;
-  const float dt = M->prm[TP_DT];
-  const float inv_dt = M->inv_dt;
+  // (PAIR: scalars - as values the compiler loads with vector loads, dt and the products it hoists out of the substep loop,
+  // 0.5 dt and 0.25 dt^2, sat in vector registers for the whole kernel and were spilled to SCRATCH: 12 MB of traffic per launch)
+  const float dt = PAIR ? uni_sgpr(M->prm[TP_DT]) : M->prm[TP_DT];
+  const float inv_dt = PAIR ? uni_sgpr(M->inv_dt) : M->inv_dt;
+  const float dt_half = PAIR ? uni_sgpr(0.5f * dt) : 0.5f * dt, dt2_quarter = PAIR ? uni_sgpr(0.25f * dt * dt) : 0.25f * dt * dt;
   const int nj = nb - 1;
   // Everything about the model is (re)read from the L2-resident struct in the phase that uses it, through an
   // opaque pointer, and every lane-derived mask / index is re-derived from an opaque copy of the lane id, so
@@ -485,7 +497,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
   // ---- per-env state: the base pose and twist are wave-uniform (SGPRs); q / qd / motor torque / target of
   // body lane b are parked in LDS (W.st) and read where a phase needs them
   float pos[3], quat[4], bv[3], bw[3];
-  const float mu = args.arr.domain ? uni(args.arr.friction[env]) : M->prm[TP_FRICTION];
+  const float mu = args.arr.domain ? uni(args.arr.friction[env]) : (PAIR ? uni_sgpr(M->prm[TP_FRICTION]) : M->prm[TP_FRICTION]);
   bool motors_on;
   int flags_in = 0, steps_in = 0;      // base row words 13 and 15 (device_model.h)
   bool do_reset = false;
@@ -592,7 +604,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
   if (!RESET) { prio_nc = flags_in & 255; set_tree_priority(0); }
 #endif
 
-  const float floor_z = M->prm[TP_FLOOR_Z], margin = M->prm[TP_CONTACT_MARGIN];
+  const float floor_z = PAIR ? uni_sgpr(M->prm[TP_FLOOR_Z]) : M->prm[TP_FLOOR_Z], margin = PAIR ? uni_sgpr(M->prm[TP_CONTACT_MARGIN]) : M->prm[TP_CONTACT_MARGIN];
   const int iters = M->n_iterations;
   int maxc = M->max_contacts;
   if (maxc > MAXC) maxc = MAXC;
@@ -1937,6 +1949,14 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
       dc[1] = make_float4(zc0[3], zc0[4], zc0[5], z00[0]);
       dc[2] = make_float4(z00[1], z00[2], z00[3], z00[4]);
       dc[3] = make_float4(z00[5], 0.f, 0.f, 0.f);
+      if (PAIR) {
+        // the sweeps' inputs of this lane's row wait in LDS while the B entries are built (the 1024 bytes of the body-record area
+        // that the z0 stash leaves): the pair form carries the LDS base of its env in a register, the B build - 64 entries, a
+        // column descriptor in flight, the row's own descriptor - is the phase with the fewest to spare, and what did not fit
+        // went to SCRATCH (12 MB of HBM traffic per launch of 4096 envs)
+        zs[64 * 6 + lt] = y; zs[64 * 7 + lt] = mhi; zs[64 * 8 + lt] = lr; zs[64 * 9 + lt] = ldir;
+        asm volatile("" : "=v"(y), "=v"(mhi), "=v"(lr), "=v"(ldir));     // (dead until they are read back)
+      }
     }
     WSYNC();
     STAMP(5);
@@ -2013,6 +2033,10 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
     // reaches the other rows as ONE v_readlane (SGPR broadcast) + ONE fma per lane. y (not z = lam + y) is
     // what is accumulated: it is small where lam is large, and the rounding of a row's own update stays in y.
     // Row order (the oracle's): limit rows (ascending joint), motor rows, then per point normal, friction x, y.
+    if (PAIR) {
+      const float *zs = reinterpret_cast<const float *>(W.body);
+      y = zs[64 * 6 + lt]; mhi = zs[64 * 7 + lt]; lr = zs[64 * 8 + lt]; ldir = zs[64 * 9 + lt];
+    }
     float lam = 0.f, lam_c = 0.f, lim_lam = 0.f;
     int dvec = 0;   // lane j: the impulse change of motor row j in the current sweep (the other lanes stay 0)
     {
@@ -2072,7 +2096,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
                #P ":\n\t"
 #define TREX_POINT_OUTS [y] "+v"(y), [dv] "+v"(dvc), [al] "+s"(alive), [t] "=&v"(pt_), [d] "=&v"(pd_), [hi] "=&v"(ph_), \
                         [snl] "=&s"(psn_), [sd] "=&s"(psd_)
-#define TREX_POINT_INS [lam] "v"(lam), [mu] "v"(mu), [thr] "v"(thr), [lnz] "s"(lamnz)
+#define TREX_POINT_INS [lam] "v"(lam), [mu] "v"(mu_v), [thr] "v"(thr), [lnz] "s"(lamnz)
 #define TREX_POINT_OPS(P, S) [b0##P] "v"(Bc[3 * (S)]), [b1##P] "v"(Bc[3 * (S) + 1]), [b2##P] "v"(Bc[3 * (S) + 2]),     \
                              [ln##P] "n"(KROW_LANE(3 * (S))), [lx##P] "n"(KROW_LANE(3 * (S) + 1)), [ly##P] "n"(KROW_LANE(3 * (S) + 2))
 // (several point slots per asm statement: the compiler closes every statement with an s_nop of its own)
@@ -2084,6 +2108,8 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
 #define TREX_POINTS1(S)                                                                                \
   asm volatile(TREX_POINT_TEXT(0) : TREX_POINT_OUTS : TREX_POINT_INS, TREX_POINT_OPS(0, S) : "vcc", "scc");
       // lanes that hold the normal row of a live point slot
+      float mu_v = mu;        // the friction coefficient as a vector operand of the point blocks
+      if (PAIR) asm volatile("" : "+v"(mu_v));     // (made HERE: hoisted out of the substep loop it was a register carried - and spilled - through the whole kernel)
       const bool is_nrm = lt >= CLANE0 && (lt - CLANE0) % 3 == 0 && (lt - CLANE0) / 3 >= s0;
       const unsigned long long nrm_mask = __ballot(is_nrm);
 #if TREX_PRIO_MODE == 1
@@ -2430,15 +2456,15 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
       // exponential map of w dt: dq = (w sin(h)/|w|, cos(h)), h = |w| dt / 2. Below h = 1/4 (|w| < 250 rad/s at
       // dt = 2 ms: every physical state) the series in h^2 are exact to f32 rounding and need neither |w| nor a
       // division: sin(h)/|w| = dt/2 (1 - h^2/6 + h^4/120 - h^6/5040 + h^8/362880)
-      const float w2 = dot3(bw, bw), h2 = 0.25f * dt * dt * w2;
+      const float w2 = dot3(bw, bw), h2 = dt2_quarter * w2;
       float dq[4];
       if (h2 < 0.0625f && !TREX_ABLATE_EXACT_QUAT) {
         const float sc = 1.f + h2 * (-1.f / 6.f + h2 * (1.f / 120.f + h2 * (-1.f / 5040.f + h2 * (1.f / 362880.f))));
-        const float sh = 0.5f * dt * sc;
+        const float sh = dt_half * sc;
         dq[0] = bw[0] * sh; dq[1] = bw[1] * sh; dq[2] = bw[2] * sh;
         dq[3] = 1.f + h2 * (-0.5f + h2 * (1.f / 24.f + h2 * (-1.f / 720.f + h2 * (1.f / 40320.f))));
       } else {
-        const float wn = sqrtf(w2), sh = wn > 1e-12f ? sinf(0.5f * wn * dt) / wn : 0.5f * dt;
+        const float wn = sqrtf(w2), sh = wn > 1e-12f ? sinf(0.5f * wn * dt) / wn : dt_half;
         dq[0] = bw[0] * sh; dq[1] = bw[1] * sh; dq[2] = bw[2] * sh; dq[3] = cosf(0.5f * wn * dt);
       }
       float o[4];
