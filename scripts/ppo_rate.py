@@ -33,5 +33,5 @@ for graphs in (False, True):
     dt = time.perf_counter() - t0
     steps = agent.total_env_steps - s0
     print("PPO %d envs, %d epochs x 32 minibatches, graphs=%d: %.3f M env-steps/s including the learner; rollout alone %.3f M; "
-          "update %.1f ms per iteration (%.3f ms per minibatch step)"
+          "update %.1f ms per iteration (%.4f ms per minibatch step)"
           % (n, epochs, graphs, steps / dt / 1e6, steps / tr / 1e6, (dt - tr) / 10 * 1e3, (dt - tr) / 10 / (epochs * 32) * 1e3), flush=True)

@@ -30,6 +30,12 @@
 
 namespace {
 
+// Every MFMA loop below takes its LDS operands in ONE batch before the first MFMA (LDS_ISSUED is a compiler fence: the reads may
+// not sink below it). Left to itself the compiler issued each read right before the MFMA that uses it - read, s_waitcnt
+// lgkmcnt(0), MFMA, 170 - 190 cycles per step instead of the MFMA's 64 (scripts/learn_phases.py: layer 1 7.8 k cycles for 40 steps).
+#define LDS_ISSUED() asm volatile("" ::: "memory")
+
+constexpr int LEARN_UF = 13;           // float4s of theta per thread of learn_grad_kernel's staging trip
 constexpr int W2S = HID + 1;           // LDS row stride of W2 (transposed reads in the backward pass)
 constexpr int XS = MAXD + 1;           // LDS row stride of the observation tile
 constexpr int TS = TILE + 1;           // LDS row stride of the [row][env] transposition buffers
@@ -38,14 +44,15 @@ constexpr int TS = TILE + 1;           // LDS row stride of the [row][env] trans
 // rows of the two W2 matrices are padded to W2S words: a global float at offset i sits at i + shift(i), where the shift
 // grows by HID after each W2 (its 64 pad words) and, inside a W2, by one per row. One flat loop stages everything.
 struct LdsLayout {
-  int X, buf, total;           // observation tile; per-wave transposition buffers; floats in all
+  int X, buf, vec, total;      // observation tile; parked tiles; small vectors; floats in all
 };
 __host__ __device__ inline LdsLayout make_lds_layout(const Layout &lay) {
   LdsLayout l{};
   int o = lay.count + 2 * HID;                         // theta + the pad words of the two W2s
   o = (o + 3) & ~3;
   l.X = o; o += TILE * XS;
-  l.buf = o; o += (4 * HID + TILE) * TS;      // parked tiles [row][env]: H1, H2 [64] | D3 [32] | D2, D1 [64]
+  l.buf = o; o += (4 * HID + 2 * TILE) * TS;  // parked tiles [row][env]: H1, H2 [64] | D3 [32] | D2, D1 [64] | DL [32]
+  l.vec = o; o += 128;                        // per-env loss terms [32] | 1 / sd per action [32] | sum of logstd [1]
   l.total = o;
   return l;
 }
@@ -66,6 +73,23 @@ struct LearnArgs {
   float cliprange, vf_coef;
   Layout lay;
 };
+
+// tanh_fast (policy_common.h) of 16 accumulator registers, stage by stage: the two quarter-rate transcendentals of one value
+// overlap with those of the others (one value after the other the chain of each costs ~165 cycles: profiles/tools/mfma_chain_bench.hip)
+__device__ __forceinline__ void tanh16(f32x16 &v) {
+  float e[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) e[r] = __builtin_amdgcn_exp2f(fabsf(v[r]) * 2.885390081777927f);
+#pragma unroll
+  for (int r = 0; r < 16; r++) e[r] = __builtin_amdgcn_rcpf(e[r] + 1.0f);
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const float x = v[r], x2 = x * x;
+    const float t = 1.0f - 2.0f * e[r];
+    const float p = x * (1.0f + x2 * (-0.3333333333f + x2 * (0.1333333333f + x2 * (-0.05396825397f))));
+    v[r] = fabsf(x) < 0.1f ? p : copysignf(t, x);
+  }
+}
 
 // sum over the 32 lanes of a half wave (same h), result on all of them: four DPP steps inside the 16-lane rows, then
 // gfx950's v_permlane16_swap (rows 0<->1, 2<->3)
@@ -96,87 +120,102 @@ __device__ __forceinline__ float half_sum(float v) {
 //   grad W1 (6 tiles, all four waves), grad b1
 // Only this net's parameters are staged (by 256 threads: one trip of loads). Every tile writes its gradient slice to
 // its own row of the partial buffer: no atomics, fixed order in the reduction.
+#if TREX_LEARN_STAMPS     // diagnostic build only: s_memtime at the barriers of every workgroup's wave 0 (scripts/learn_phases.py)
+__device__ unsigned long long learn_stamps[512 * 12];
+#define LSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) learn_stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 12 + (i)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define LSTAMP(i) do {} while (0)
+#endif
 __global__ __launch_bounds__(256) void learn_grad_kernel(LearnArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  LSTAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, net = blockIdx.y;     // net 0: policy, 1: value
   const int D = g.lay.D, A = g.lay.A;
   const LdsLayout L = make_lds_layout(g.lay);
-  // ---- stage this net's parameters (the LDS image keeps theta's layout, lds_of; the other net's part stays unwritten):
-  // policy = [pW1, vW1) + logstd, value = [vW1, logstd)
-  {
-    const float4 *s4 = reinterpret_cast<const float4 *>(g.theta);
-    const int lo4 = (net ? g.lay.vW1 : 0) >> 2, hi4 = (net ? g.lay.logstd : g.lay.vW1) >> 2;
-    const int ls4 = g.lay.logstd >> 2, le4 = g.lay.count >> 2;
-    const int n4 = (hi4 - lo4) + (net ? 0 : le4 - ls4);
-    constexpr int UF = 12;                               // 2 670 float4s by 256 threads: one trip
-    for (int i0 = tid; i0 < n4; i0 += 256 * UF) {
-      float4 t[UF];
-      int src[UF];
-#pragma unroll
-      for (int u = 0; u < UF; u++) {
-        const int i = i0 + 256 * u;
-        src[u] = i < hi4 - lo4 ? lo4 + i : ls4 + (i - (hi4 - lo4));
-        t[u] = s4[i < n4 ? src[u] : lo4];
-      }
-#pragma unroll
-      for (int u = 0; u < UF; u++) {
-        if (i0 + 256 * u < n4) {
-          float *d = lds + lds_of(g.lay, 4 * src[u]);
-          d[0] = t[u].x; d[1] = t[u].y; d[2] = t[u].z; d[3] = t[u].w;
-        }
-      }
-    }
-  }
+  // ---- staging. Three global round trips feed the first barrier - the tile's sample rows (perm), this net's parameters, the
+  // observation rows of those samples (which need the perm values) - and they are issued so that they overlap: perm first, the
+  // parameters behind it, one barrier for the row table while the parameters are in flight, then the observations, and only
+  // then the LDS writes of the parameters (loads return in order: the wait for the row table does not wait for theta).
+  // The LDS image keeps theta's layout (lds_of; the other net's part stays unwritten): policy = [pW1, vW1) + logstd, value = [vW1, logstd)
   const int s0 = blockIdx.x * TILE;                       // first sample of the tile within the minibatch
   float *X = lds + L.X;
   constexpr int XC = 96;                                  // columns of X that the weight-gradient tiles read (3 x 32)
-  {
-    __shared__ long long tile_rows[TILE];
-    if (tid < TILE) tile_rows[tid] = s0 + tid < g.mb ? g.perm[g.first + s0 + tid] : -1;
-    __syncthreads();
-    constexpr int UX = 12;                                // TILE * XC / 256 = 12 elements per thread: one trip
-    for (int idx0 = tid; idx0 < TILE * XC; idx0 += 256 * UX) {
-      float raw[UX];
+  __shared__ long long tile_rows[TILE];
+  // (No control flow between the first load and the barrier that opens layer 1: loads under a branch make the compiler wait for
+  // EVERY outstanding load at the join - s_waitcnt vmcnt(0) - and the overlap is gone. Out-of-range lanes read a clamped address
+  // and select afterwards, out-of-range LDS writes go to a dump slot.)
+  const long long my_row_raw = g.perm[g.first + min(s0 + min(tid, TILE - 1), g.mb - 1)];
+  const long long my_row = (s0 + tid < g.mb) ? my_row_raw : -1;
+  constexpr int UF = LEARN_UF;                            // 2 670 float4s by 256 threads: ONE trip (the host entry checks)
+  float4 tp[UF];
+  int src[UF];
+  const float4 *s4 = reinterpret_cast<const float4 *>(g.theta);
+  const int lo4 = (net ? g.lay.vW1 : 0) >> 2, hi4 = (net ? g.lay.logstd : g.lay.vW1) >> 2;
+  const int ls4 = g.lay.logstd >> 2, le4 = g.lay.count >> 2;
+  const int n4 = (hi4 - lo4) + (net ? 0 : le4 - ls4);
+  // (measured, not kept: layer 1 started on W1 and b1 alone, the rest of the parameters landing during it and written to LDS
+  // before the next barrier - no gain: the observation rows, which wait for the row table, arrive last either way)
 #pragma unroll
-      for (int u = 0; u < UX; u++) {
-        const int idx = idx0 + 256 * u, ii = idx / XC, kk = idx - ii * XC;
-        const long long row = idx < TILE * XC ? tile_rows[ii] : -1;
-        raw[u] = (kk < D && row >= 0) ? g.obs[(size_t)row * D + kk] : 0.f;
-      }
+  for (int u = 0; u < UF; u++) {
+    const int i = tid + 256 * u;
+    src[u] = i < hi4 - lo4 ? lo4 + i : ls4 + (i - (hi4 - lo4));
+    src[u] = i < n4 ? src[u] : lo4;
+  }
 #pragma unroll
-      for (int u = 0; u < UX; u++) {
-        const int idx = idx0 + 256 * u, ii = idx / XC, kk = idx - ii * XC;
-        if (idx < TILE * XC) X[ii * XS + kk] = raw[u];
-      }
-    }
+  for (int u = 0; u < UF; u++) tp[u] = s4[src[u]];
+  LDS_ISSUED();
+  if (tid < TILE) tile_rows[tid] = my_row;
+  __syncthreads();
+  LSTAMP(9);
+  constexpr int UX = 12;                                  // TILE * XC / 256 = 12 elements per thread: one trip
+  float raw[UX];
+#pragma unroll
+  for (int u = 0; u < UX; u++) {
+    const int idx = tid + 256 * u, ii = idx / XC, kk = idx - ii * XC;
+    const long long row = tile_rows[ii];
+    const float v = g.obs[(size_t)(row >= 0 ? row : 0) * D + (kk < D ? kk : D - 1)];
+    raw[u] = (kk < D && row >= 0) ? v : 0.f;
   }
   const int col = lane & 31, h = lane >> 5;
   const bool valid = s0 + col < g.mb;
-  // the sample's loss inputs (wave 0 runs the output layer and the loss), fetched NOW: their round trips hide behind the staging wait and the forward pass
+  // the sample's loss inputs (wave 0 runs the output layer and the loss), fetched NOW by every wave (a branch around the loads
+  // would cost the overlap, above; left inside `if (wave == 0)` the compiler also SANK them to their use after the second
+  // barrier, a full round trip in the middle of the chain): their round trips hide behind the staging
   f32x16 act_in;
-  float adv_in = 0.f, logp0_in = 0.f, val0_in = 0.f, ret_in = 0.f, advm = 0.f, advr = 0.f;
+  float adv_in, logp0_in, val0_in, ret_in, advm, advr;
+  {
+    const long long sidx_raw = tile_rows[col];
+    const long long sidx = sidx_raw >= 0 ? sidx_raw : 0;
 #pragma unroll
-  for (int r = 0; r < 16; r++) act_in[r] = 0.f;
-  if (wave == 0) {
-    const long long sidx = valid ? g.perm[g.first + s0 + col] : 0;
-    if (net == 0) {
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int a = rowmap(r, h);
-        if (a < A && valid) act_in[r] = g.act[(size_t)sidx * A + a];
-      }
-      if (valid) { adv_in = g.adv[sidx]; logp0_in = g.logp0[sidx]; }
-      advm = g.adv_stats[0]; advr = g.adv_stats[1];
-    } else if (valid) {
-      val0_in = g.val0[sidx]; ret_in = g.ret[sidx];
+    for (int r = 0; r < 16; r++) {
+      const int a = rowmap(r, h);
+      act_in[r] = g.act[(size_t)sidx * A + (a < A ? a : A - 1)];
     }
+    adv_in = g.adv[sidx]; logp0_in = g.logp0[sidx]; val0_in = g.val0[sidx]; ret_in = g.ret[sidx];
+    advm = g.adv_stats[0]; advr = g.adv_stats[1];
   }
+  float *VEC = lds + L.vec;             // [0..31] per-env loss term | [32..63] 1 / sd per action | [64] sum of logstd | [96..99] dump slot
+  const float ls_raw = g.theta[g.lay.logstd + (lane < A ? lane : A - 1)];      // (policy net, wave 3 uses it) logstd of action `lane`
+  LDS_ISSUED();
+#pragma unroll
+  for (int u = 0; u < UF; u++) {
+    float *d = lds + (tid + 256 * u < n4 ? lds_of(g.lay, 4 * src[u]) : L.vec + 96);
+    d[0] = tp[u].x; d[1] = tp[u].y; d[2] = tp[u].z; d[3] = tp[u].w;
+  }
+#pragma unroll
+  for (int u = 0; u < UX; u++) {
+    const int idx = tid + 256 * u, ii = idx / XC, kk = idx - ii * XC;
+    X[ii * XS + kk] = raw[u];
+  }
+  // (the loss inputs are pinned to registers HERE - without this the compiler sinks the loads to their use)
+  asm volatile("" : "+v"(act_in), "+v"(adv_in), "+v"(logp0_in), "+v"(val0_in), "+v"(ret_in));
   __syncthreads();
+  LSTAMP(1);
   const float *W1 = lds + lds_of(g.lay, net ? g.lay.vW1 : g.lay.pW1), *b1 = lds + lds_of(g.lay, net ? g.lay.vb1 : g.lay.pb1);
   const float *W2 = lds + lds_of(g.lay, net ? g.lay.vW2 : g.lay.pW2), *b2 = lds + lds_of(g.lay, net ? g.lay.vb2 : g.lay.pb2);
   const float *W3 = lds + lds_of(g.lay, net ? g.lay.vW3 : g.lay.pW3), *b3 = lds + lds_of(g.lay, net ? g.lay.vb3 : g.lay.pb3);
   // parked tiles, [row][env] with a row stride of TS words: H1, H2 (activations), D3, D2, D1 (deltas); DV = D3 (value net: dv[env])
-  float *H1 = lds + L.buf, *H2 = H1 + HID * TS, *D3 = H2 + HID * TS, *D2 = D3 + TILE * TS, *D1 = D2 + HID * TS;
+  float *H1 = lds + L.buf, *H2 = H1 + HID * TS, *D3 = H2 + HID * TS, *D2 = D3 + TILE * TS, *D1 = D2 + HID * TS, *DL = D1 + HID * TS;
   float *out = g.partial + (size_t)blockIdx.x * g.stride;
   const float inv_mb = 1.0f / (float)g.mb;
   const int Dp8 = (D + 7) & ~7;     // (<= XC: the host entry refuses obs_dim > 96)
@@ -188,11 +227,15 @@ __global__ __launch_bounds__(256) void learn_grad_kernel(LearnArgs g) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    float pa[16], pb[16];
 #pragma unroll
     for (int s = 0; s < 16; s++) {
       const int env = 2 * s + h;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Pa[col * sa_row + env * sa_env], Pb[col * TS + env], acc, 0, 0, 0);
+      pa[s] = Pa[col * sa_row + env * sa_env]; pb[s] = Pb[col * TS + env];
     }
+    LDS_ISSUED();
+#pragma unroll
+    for (int s = 0; s < 16; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s], pb[s], acc, 0, 0, 0);
     if (col < cols) {
 #pragma unroll
       for (int r = 0; r < 16; r++)
@@ -200,10 +243,10 @@ __global__ __launch_bounds__(256) void learn_grad_kernel(LearnArgs g) {
     }
   };
   // sum over the 32 envs of row `lane` of a parked tile (bias gradients), fixed order
-  auto row_sum = [&](const float *P) {
+  auto row_sum = [&](const float *P, int row_mask = 63) {      // (row_mask 31: a 32-row tile, lanes 32.. repeat rows 0..)
     float t = 0.f;
 #pragma unroll
-    for (int e = 0; e < TILE; e++) t += P[lane * TS + e];
+    for (int e = 0; e < TILE; e++) t += P[(lane & row_mask) * TS + e];
     return t;
   };
   const int u = wave & 1;                  // chain waves: the half of the neurons this wave owns
@@ -214,72 +257,99 @@ __global__ __launch_bounds__(256) void learn_grad_kernel(LearnArgs g) {
   if (chain) {
 #pragma unroll
     for (int r = 0; r < 16; r++) h1o[r] = b1[32 * u + rowmap(r, h)];
-    for (int k0 = 0; k0 < Dp8; k0 += 8) {                // four k-steps per trip (policy_step.hip, act_kernel)
-      float a[4], b[4];
+    // k-steps in chunks of four (8 columns; policy_step.hip, act_kernel: the same order of accumulation); all operands first
+    const int nch = Dp8 >> 3;                            // <= XC / 8 = 12
+    float wa[48], xb[48];
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int k = k0 + 2 * j + h;
-        b[j] = X[col * XS + k];                          // (zero from column D on; XC = 96 columns are staged)
-        const int kc = k < D ? k : D - 1;
-        a[j] = W1[kc * HID + 32 * u + col];
+    for (int c = 0; c < 12; c++) {
+      if (c < nch) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int k = 8 * c + 2 * j + h;
+          xb[4 * c + j] = X[col * XS + k];               // (zero from column D on; XC = 96 columns are staged)
+          const int kc = k < D ? k : D - 1;
+          wa[4 * c + j] = W1[kc * HID + 32 * u + col];
+        }
       }
-#pragma unroll
-      for (int j = 0; j < 4; j++) h1o = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], h1o, 0, 0, 0);
     }
+    LDS_ISSUED();
 #pragma unroll
-    for (int r = 0; r < 16; r++) { h1o[r] = tanh_fast(h1o[r]); H1[(32 * u + rowmap(r, h)) * TS + col] = h1o[r]; }
+    for (int c = 0; c < 12; c++) {
+      if (c < nch) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) h1o = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[4 * c + j], xb[4 * c + j], h1o, 0, 0, 0);
+      }
+    }
+    tanh16(h1o);
+#pragma unroll
+    for (int r = 0; r < 16; r++) H1[(32 * u + rowmap(r, h)) * TS + col] = h1o[r];
+  }
+  if (net == 0 && wave == 3) {
+    // 1 / sd of every action and the sum of logstd, once per workgroup (until round 4 the loss took 16 expf per lane)
+    const float ls_in = lane < A ? ls_raw : 0.f;
+    if (lane < 32) VEC[32 + lane] = lane < A ? expf(-ls_in) : 0.f;
+    const float sl = half_sum(lane < 32 ? ls_in : 0.f);
+    if (lane == 0) VEC[64] = sl;
   }
   __syncthreads();     // ---- B1: H1 is parked
+  LSTAMP(2);
   // ================================================================ forward, layer 2 (own half; k ascending: t = 0, 1)
   if (chain) {
 #pragma unroll
     for (int r = 0; r < 16; r++) h2o[r] = b2[32 * u + rowmap(r, h)];
+    float wa[32], hb[16];
+#pragma unroll
+    for (int s = 0; s < 32; s++) wa[s] = W2[(32 * (s >> 4) + rowmap(s & 15, h)) * W2S + 32 * u + col];
+#pragma unroll
+    for (int s = 0; s < 16; s++) hb[s] = H1[(32 * (1 - u) + rowmap(s, h)) * TS + col];      // the half the other chain wave owns
+    LDS_ISSUED();
 #pragma unroll
     for (int t = 0; t < 2; t++) {
       if (t == u) {
 #pragma unroll
-        for (int s = 0; s < 16; s++)
-          h2o = __builtin_amdgcn_mfma_f32_32x32x2f32(W2[(32 * t + rowmap(s, h)) * W2S + 32 * u + col], h1o[s], h2o, 0, 0, 0);
+        for (int s = 0; s < 16; s++) h2o = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[16 * t + s], h1o[s], h2o, 0, 0, 0);
       } else {
 #pragma unroll
-        for (int s = 0; s < 16; s++)
-          h2o = __builtin_amdgcn_mfma_f32_32x32x2f32(W2[(32 * t + rowmap(s, h)) * W2S + 32 * u + col], H1[(32 * t + rowmap(s, h)) * TS + col], h2o, 0, 0, 0);
+        for (int s = 0; s < 16; s++) h2o = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[16 * t + s], hb[s], h2o, 0, 0, 0);
       }
     }
+    tanh16(h2o);
 #pragma unroll
-    for (int r = 0; r < 16; r++) { h2o[r] = tanh_fast(h2o[r]); H2[(32 * u + rowmap(r, h)) * TS + col] = h2o[r]; }
+    for (int r = 0; r < 16; r++) H2[(32 * u + rowmap(r, h)) * TS + col] = h2o[r];
   }
   __syncthreads();     // ---- B2: H2 is parked
+  LSTAMP(3);
   // ================================================================ wave 0: output layer, loss, delta3 (policy) / dv (value)
   if (wave == 0) {
     if (net == 0) {
       f32x16 mu;
 #pragma unroll
       for (int r = 0; r < 16; r++) { const int a = rowmap(r, h); mu[r] = a < A ? b3[a] : 0.f; }
+      float wa[32], hb[16];
 #pragma unroll
-      for (int s = 0; s < 16; s++)
-        mu = __builtin_amdgcn_mfma_f32_32x32x2f32(col < A ? W3[rowmap(s, h) * A + col] : 0.f, h2o[s], mu, 0, 0, 0);
+      for (int s = 0; s < 32; s++) wa[s] = W3[(32 * (s >> 4) + rowmap(s & 15, h)) * A + (col < A ? col : A - 1)];      // (unconditional reads: no exec-mask branches)
 #pragma unroll
-      for (int s = 0; s < 16; s++)
-        mu = __builtin_amdgcn_mfma_f32_32x32x2f32(col < A ? W3[(32 + rowmap(s, h)) * A + col] : 0.f, H2[(32 + rowmap(s, h)) * TS + col], mu, 0, 0, 0);
-      const float *ls = lds + lds_of(g.lay, g.lay.logstd);
+      for (int s = 0; s < 16; s++) hb[s] = H2[(32 + rowmap(s, h)) * TS + col];
+      LDS_ISSUED();
+#pragma unroll
+      for (int s = 0; s < 32; s++) wa[s] = col < A ? wa[s] : 0.f;
+#pragma unroll
+      for (int s = 0; s < 16; s++) mu = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[s], h2o[s], mu, 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 16; s++) mu = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[16 + s], hb[s], mu, 0, 0, 0);
+      LSTAMP(8);
       f32x16 z, isd;
-      float zz = 0.f, sum_ls = 0.f;
+      float zz = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int a = rowmap(r, h);
-        z[r] = 0.f; isd[r] = 0.f;
-        if (a < A) {
-          const float l = ls[a];
-          sum_ls += l;
-          isd[r] = expf(-l);
-          const float ac = valid ? act_in[r] : mu[r];
-          z[r] = (ac - mu[r]) * isd[r];
-          zz = __builtin_fmaf(z[r], z[r], zz);
-        }
+        isd[r] = VEC[32 + a];                           // 0 beyond the last action
+        const float ac = valid ? act_in[r] : mu[r];
+        z[r] = (ac - mu[r]) * isd[r];
+        zz = __builtin_fmaf(z[r], z[r], zz);
       }
       zz += __shfl_xor(zz, 32, 64);
-      sum_ls += __shfl_xor(sum_ls, 32, 64);
+      const float sum_ls = VEC[64];
       const float logp = -0.5f * zz - sum_ls - 0.5f * LOG_2PI * (float)A;
       const float an = valid ? (adv_in - advm) * advr : 0.f;
       const float ratio = valid ? expf(logp - logp0_in) : 1.f;
@@ -288,19 +358,16 @@ __global__ __launch_bounds__(256) void learn_grad_kernel(LearnArgs g) {
       const bool through = l1 >= l2 || rc == ratio;      // the branch of max() that carries a gradient w.r.t. ratio
       const float dlogp = valid && through ? -an * ratio * inv_mb : 0.f;     // dL/dlogp = dL/dratio * ratio
       // L_pg = mean(max(-a r, -a clip(r))), r = exp(logp - logp0): dL/dlogp = (-a) r / mb on the live branch;
-      // dlogp/dmu = z / sd; dlogp/dlogstd = z^2 - 1
-      float pg = valid ? fmaxf(l1, l2) : 0.f;
+      // dlogp/dmu = z / sd; dlogp/dlogstd = z^2 - 1. The sums over the tile's samples (grad b3, grad logstd, the surrogate term)
+      // are taken by the helper waves from the parked tiles, beside delta 2 (until round 4: 35 DPP reductions right here)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int a = rowmap(r, h);
         d3[r] = dlogp * z[r] * isd[r];
-        D3[rowmap(r, h) * TS + col] = d3[r];
-        const float gl = half_sum(a < A ? dlogp * (z[r] * z[r] - 1.f) : 0.f);      // d/dlogstd, summed over the tile's samples
-        const float gb = half_sum(d3[r]);
-        if (col == 0 && a < A) { out[g.lay.logstd + a] = gl; out[g.lay.pb3 + a] = gb; }
+        D3[a * TS + col] = d3[r];
+        DL[a * TS + col] = a < A ? dlogp * (z[r] * z[r] - 1.f) : 0.f;
       }
-      pg = half_sum(h == 0 ? pg : 0.f);
-      if (lane == 0) out[g.stride - 4] = pg;              // sum of the tile's surrogate terms (the mean is taken later)
+      if (h == 0) VEC[col] = valid ? fmaxf(l1, l2) : 0.f;
     } else {
       // ---- value head: v = w . h2 + b (k ascending); clipped value loss; its gradients are rank-1 in the sample
       float v = 0.f;
@@ -317,13 +384,11 @@ __global__ __launch_bounds__(256) void learn_grad_kernel(LearnArgs g) {
       // 0.5 mean(max(e1, e2)): gradient (v - R) on the unclipped branch, (vclip - R) [clip inactive] on the other
       dv = e1 >= e2 ? (v - rt) : ((dvc == v - v0) ? (vclip - rt) : 0.f);
       dv = valid ? g.vf_coef * dv * inv_mb : 0.f;
-      const float vl = half_sum((valid && h == 0) ? 0.5f * fmaxf(e1, e2) : 0.f);
-      const float gb = half_sum(h == 0 ? dv : 0.f);
-      if (lane == 0) { out[g.stride - 3] = vl; out[g.lay.vb3] = gb; }
-      if (h == 0) D3[col] = dv;                           // DV[env] for wave 1
+      if (h == 0) { D3[col] = dv; VEC[col] = valid ? 0.5f * fmaxf(e1, e2) : 0.f; }     // DV[env], the env's loss term: for waves 1 - 3
     }
   }
   __syncthreads();     // ---- B3: D3 (policy) / dv (value) is parked
+  LSTAMP(4);
   // ================================================================ delta of layer 2 (own half)  |  grad W3
   if (chain) {
     if (net == 0) {
@@ -331,18 +396,22 @@ __global__ __launch_bounds__(256) void learn_grad_kernel(LearnArgs g) {
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[r] = 0.f;
+      float wa[16], db[16];
+#pragma unroll
+      for (int s = 0; s < 16; s++) {
+        const int a = rowmap(s, h);
+        wa[s] = W3[(32 * u + col) * A + (a < A ? a : A - 1)];
+        db[s] = D3[a * TS + col];                           // (wave 0 holds the same values in d3)
+      }
+      LDS_ISSUED();
+#pragma unroll
+      for (int s = 0; s < 16; s++) wa[s] = rowmap(s, h) < A ? wa[s] : 0.f;
       if (wave == 0) {
 #pragma unroll
-        for (int s = 0; s < 16; s++) {
-          const int a = rowmap(s, h);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a < A ? W3[(32 * u + col) * A + a] : 0.f, d3[s], acc, 0, 0, 0);
-        }
+        for (int s = 0; s < 16; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[s], d3[s], acc, 0, 0, 0);
       } else {
 #pragma unroll
-        for (int s = 0; s < 16; s++) {
-          const int a = rowmap(s, h);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a < A ? W3[(32 * u + col) * A + a] : 0.f, D3[a * TS + col], acc, 0, 0, 0);
-        }
+        for (int s = 0; s < 16; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[s], db[s], acc, 0, 0, 0);
       }
 #pragma unroll
       for (int r = 0; r < 16; r++) d2o[r] = acc[r] * (1.f - h2o[r] * h2o[r]);
@@ -351,34 +420,56 @@ __global__ __launch_bounds__(256) void learn_grad_kernel(LearnArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int k = 32 * u + rowmap(r, h);
-        const float gw = half_sum(h2o[r] * dv);                // grad W3[k] = sum_env h2[env][k] dv[env]
-        if (col == 0) out[g.lay.vW3 + k] = gw;
         d2o[r] = W3[k] * dv * (1.f - h2o[r] * h2o[r]);
       }
     }
 #pragma unroll
     for (int r = 0; r < 16; r++) D2[(32 * u + rowmap(r, h)) * TS + col] = d2o[r];
   } else if (net == 0) {
-    // ---- grad W3[n2][a] = sum_env h2[env][n2] d3[env][a]: row tile (wave - 2) of H2 against D3
+    // ---- grad W3[n2][a] = sum_env h2[env][n2] d3[env][a]: row tile (wave - 2) of H2 against D3; the sums over the samples
     wgrad(H2 + 32 * (wave - 2) * TS, TS, 1, D3, g.lay.pW3 + 32 * (wave - 2) * A, A, 32, A);
+    if (wave == 2) {
+      const float gb = row_sum(D3, 31);
+      if (lane < A) out[g.lay.pb3 + lane] = gb;
+    } else {
+      const float gl = row_sum(DL, 31);
+      if (lane < A) out[g.lay.logstd + lane] = gl;
+      const float pg = half_sum(lane < 32 ? VEC[lane] : 0.f);
+      if (lane == 0) out[g.stride - 4] = pg;              // sum of the tile's surrogate terms (the mean is taken later)
+    }
+  } else if (wave == 2) {
+    // ---- value net: grad W3[k] = sum_env h2[env][k] dv[env] (lane = k)
+    float gw = 0.f;
+#pragma unroll
+    for (int e = 0; e < TILE; e++) gw = __builtin_fmaf(H2[lane * TS + e], D3[e], gw);
+    out[g.lay.vW3 + lane] = gw;
+  } else {
+    const float dv_l = lane < 32 ? D3[lane] : 0.f, vl_l = lane < 32 ? VEC[lane] : 0.f;
+    const float gb = half_sum(dv_l), vl = half_sum(vl_l);
+    if (lane == 0) { out[g.stride - 3] = vl; out[g.lay.vb3] = gb; }
   }
   __syncthreads();     // ---- B4: D2 is parked
+  LSTAMP(5);
   // ================================================================ delta of layer 1 (own half)  |  grad W2, grad b2
   if (chain) {
     // d1^T = (W2 d2^T) * (1 - h1^2); W2 read transposed (row stride 65: conflict-free); k ascending: t = 0, 1
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    float wa[32], db[16];
+#pragma unroll
+    for (int s = 0; s < 32; s++) wa[s] = W2[(32 * u + col) * W2S + 32 * (s >> 4) + rowmap(s & 15, h)];
+#pragma unroll
+    for (int s = 0; s < 16; s++) db[s] = D2[(32 * (1 - u) + rowmap(s, h)) * TS + col];
+    LDS_ISSUED();
 #pragma unroll
     for (int t = 0; t < 2; t++) {
       if (t == u) {
 #pragma unroll
-        for (int s = 0; s < 16; s++)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W2[(32 * u + col) * W2S + 32 * t + rowmap(s, h)], d2o[s], acc, 0, 0, 0);
+        for (int s = 0; s < 16; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[16 * t + s], d2o[s], acc, 0, 0, 0);
       } else {
 #pragma unroll
-        for (int s = 0; s < 16; s++)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W2[(32 * u + col) * W2S + 32 * t + rowmap(s, h)], D2[(32 * t + rowmap(s, h)) * TS + col], acc, 0, 0, 0);
+        for (int s = 0; s < 16; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[16 * t + s], db[s], acc, 0, 0, 0);
       }
     }
 #pragma unroll
@@ -392,12 +483,14 @@ __global__ __launch_bounds__(256) void learn_grad_kernel(LearnArgs g) {
     if (wave == 3) out[ob2 + lane] = row_sum(D2);
   }
   __syncthreads();     // ---- B5: D1 is parked
+  LSTAMP(6);
   // ---- grad W1[k][n1] = sum_env x[env][k] d1[env][n1]: six tiles (q, v) over the four waves; grad b1 = row sums of D1
   for (int t = wave; t < 6; t += 4) {
     const int q = t >> 1, v = t & 1;
     wgrad(X + 32 * q, 1, XS, D1 + 32 * v * TS, oW1 + 32 * q * HID + 32 * v, HID, D - 32 * q, 32);
   }
   if (wave == 2) out[ob1 + lane] = row_sum(D1);
+  LSTAMP(7);
 }
 
 // ---------------------------------------------------------------- advantage statistics of every minibatch of an epoch
@@ -549,6 +642,12 @@ __global__ __launch_bounds__(256) void learn_adam_kernel(ApplyArgs g, int reduce
 
 extern "C" {
 
+#if TREX_LEARN_STAMPS
+__attribute__((visibility("default"))) int trex_policy_debug_learn_stamps(unsigned long long *host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(learn_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#endif
+
 int trex_policy_minibatch_stats(TrexPolicy *p, const float *adv_dev, int64_t num_samples, const int64_t *perm_dev, int num_minibatches,
                                 int mb, float *stats_out_dev, void *stream) {
   if (!p || !adv_dev || !perm_dev || !stats_out_dev || num_minibatches <= 0 || mb <= 0 || num_samples <= 0)
@@ -574,6 +673,8 @@ static int launch_minibatch_grad(TrexPolicy *p, const char *who, float *theta_de
     return trex_fail(TREX_E_INVALID, std::string(who) + ": null argument");
   if (mb <= 0 || first < 0 || num_samples <= 0) return trex_fail(TREX_E_INVALID, std::string(who) + ": bad sizes");
   if (p->D > 96) return trex_fail(TREX_E_INVALID, std::string(who) + ": the learner stages 96 observation columns (obs_dim <= 96)");
+  if ((p->lay.vW1 + (p->lay.count - p->lay.logstd)) / 4 > 256 * LEARN_UF || (p->lay.logstd - p->lay.vW1) / 4 > 256 * LEARN_UF)
+    return trex_fail(TREX_E_INVALID, std::string(who) + ": the learner stages one net's parameters in one trip of 256 x 13 float4s");
   const size_t P = (size_t)p->lay.count, N = (size_t)num_samples;
   BUF_TRY(theta_dev, P * sizeof(float), "minibatch step: theta");
   BUF_TRY(grad_dev, P * sizeof(float), "minibatch step: grad");

@@ -51,6 +51,9 @@
 #ifndef TREX_STAMPS
 #define TREX_STAMPS 0
 #endif
+#ifndef TREX_PAIR_MAX
+#define TREX_PAIR_MAX 4096                   // largest (even) batch the pair form steps
+#endif
 #ifndef TREX_PAIR_LAUNCH
 #define TREX_PAIR_LAUNCH (!TREX_STAMPS)      // 0: every batch through the single-env launch (A/B builds; the stamped diagnostic build)
 #endif
@@ -76,7 +79,7 @@
     __builtin_amdgcn_sched_barrier(0);                                                    \
     const unsigned long long _t = __builtin_amdgcn_s_memtime();                           \
     __builtin_amdgcn_s_waitcnt(0xC07F);                                                   \
-    if (args.debug && threadIdx.x == 0) args.debug[4096 + (i) * args.n_envs + wg] += (float)(_t - stamp_last); \
+    if (args.debug && (threadIdx.x & 63) == 0) args.debug[4096 + (i) * args.n_envs + wg] += (float)(_t - stamp_last); \
     stamp_last = _t;                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                    \
   } while (0)
@@ -657,7 +660,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
 #if TREX_STAMPS
   unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
   int stamp_alive = 0, stamp_lamnz = 0;
-  if (args.debug && threadIdx.x == 0) args.debug[4096 + 11 * args.n_envs + wg] = (float)env;   // the env of this wave
+  if (args.debug && (threadIdx.x & 63) == 0) args.debug[4096 + 11 * args.n_envs + wg] = (float)env;   // the env of this wave
 #endif
   // Episode limit of the harness (the reference never terminates, trex_env.py:183-184; a VecEnv auto-resets): the env
   // whose count reaches the limit with this step finishes the step - reward, done = 1 - and then, IN THE SAME LAUNCH,
@@ -815,7 +818,11 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
     }
     }   // act (kinematics)
     STAMP(0);
-    if (PAIR) __syncthreads();      // both envs' body records, state rows, rotations, twists and heights are in LDS
+    if (PAIR) { __syncthreads(); SUBSTAMP(16); }      // both envs' body records, state rows, rotations, twists and heights are in LDS
+    // (measured, not kept: FEEDBACK by arrival order at this barrier - the later wave of the pair one level up in its next sweeps,
+    // the earlier one down: 11.73 against 11.69 M at 4096 envs, 6.72 against 6.75 M at 2048; the stamped pair build shows the heavy
+    // env's wave waiting here 11 % of its time for the light env's wave, whose sweeps the priorities starve - but a waiting wave's
+    // issue slots go to its SIMD mates, so levelling the pair moves nothing)
     // (measured, not kept: both waves at the priority of the pair's heavier env between the two barriers - 11.69 against 11.67 M
     // at 4096 envs, 6.73 against 6.94 M at 2048)
     // ROLES (PAIR): wave 1 generates the contacts of BOTH envs, one after the other, WHILE wave 0 runs the lane-per-body
@@ -1801,7 +1808,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
 #undef REAXIS2
 #undef RETREE2
       }
-      if (PAIR) __syncthreads(); else WSYNC();      // records (U/D, 1/D, u/D, updated rates), base factor and base acceleration are in LDS
+      if (PAIR) { SUBSTAMP(17); __syncthreads(); SUBSTAMP(18); } else WSYNC();      // records (U/D, 1/D, u/D, updated rates), base factor and base acceleration are in LDS
       if (act) {
         nc = uni(__float_as_int(W.xch[35]));
         const float *x = W.xch + 8;      // (every lane reads the same words: LDS broadcast)
@@ -2488,7 +2495,7 @@ __device__ __forceinline__ void trex_step_body(const KernelArgs &args, const int
   }
 
 #if TREX_STAMPS
-  if (args.debug && threadIdx.x == 0) {
+  if (args.debug && (threadIdx.x & 63) == 0) {
     args.debug[4096 + 14 * args.n_envs + wg] = (float)stamp_alive;
     args.debug[4096 + 15 * args.n_envs + wg] = (float)stamp_lamnz;
   }
@@ -2760,10 +2767,11 @@ hipError_t trex_launch_step(const TrexDeviceModel *model, TrexBatchArrays arr, i
                1, 0, pen_in_rows};
 
 #if TREX_STAMPS   // diagnostic build: the PRODUCT instantiation, stamped (the dump of <false, true> would change its code)
-  hipLaunchKernelGGL((trex_step_kernel<false, false>), dim3(n), dim3(64), 0, stream, a);
+  if (TREX_PAIR_LAUNCH && (n & 1) == 0 && n <= TREX_PAIR_MAX) hipLaunchKernelGGL(trex_step_pair_kernel, dim3(n / 2), dim3(128), 0, stream, a);
+  else hipLaunchKernelGGL((trex_step_kernel<false, false>), dim3(n), dim3(64), 0, stream, a);
 #else
   if (debug) hipLaunchKernelGGL((trex_step_kernel<false, true>), dim3(n), dim3(64), 0, stream, a);
-  else if (TREX_PAIR_LAUNCH && (n & 1) == 0 && n <= 4096) hipLaunchKernelGGL(trex_step_pair_kernel, dim3(n / 2), dim3(128), 0, stream, a);
+  else if (TREX_PAIR_LAUNCH && (n & 1) == 0 && n <= TREX_PAIR_MAX) hipLaunchKernelGGL(trex_step_pair_kernel, dim3(n / 2), dim3(128), 0, stream, a);
   else hipLaunchKernelGGL((trex_step_kernel<false, false>), dim3(n), dim3(64), 0, stream, a);
 #endif
   return hipGetLastError();
@@ -2834,7 +2842,7 @@ hipError_t trex_launch_copy_mass_scale(const float *src, float *dst, int n, int 
 
 // launch shape of the step launch for a batch of n envs (trex_batch_launch_info): two envs per workgroup - the pair form - for an
 // even batch that is resident at once, one otherwise
-int trex_step_envs_per_workgroup(int n) { return (TREX_PAIR_LAUNCH && (n & 1) == 0 && n <= 4096) ? 2 : 1; }
+int trex_step_envs_per_workgroup(int n) { return (TREX_PAIR_LAUNCH && (n & 1) == 0 && n <= TREX_PAIR_MAX) ? 2 : 1; }
 int trex_step_lds_bytes(int n) { return trex_step_envs_per_workgroup(n) == 2 ? (int)(2 * sizeof(WaveLds) + sizeof(CgLds)) : (int)sizeof(WaveLds); }
 
 }  // extern "C"
