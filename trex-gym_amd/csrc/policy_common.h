@@ -47,6 +47,28 @@ __device__ __forceinline__ float tanh_fast(float x) {
   return ax < 0.1f ? p : copysignf(t, x);
 }
 
+// tanh_fast of 16 accumulator registers, stage by stage: the two quarter-rate transcendentals of one value
+// overlap with those of the others (one value after the other the chain of each costs ~165 cycles: profiles/tools/mfma_chain_bench.hip)
+__device__ __forceinline__ void tanh16(f32x16 &v) {
+  float e[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) e[r] = __builtin_amdgcn_exp2f(fabsf(v[r]) * 2.885390081777927f);
+#pragma unroll
+  for (int r = 0; r < 16; r++) e[r] = __builtin_amdgcn_rcpf(e[r] + 1.0f);
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const float x = v[r], x2 = x * x;
+    const float t = 1.0f - 2.0f * e[r];
+    const float p = x * (1.0f + x2 * (-0.3333333333f + x2 * (0.1333333333f + x2 * (-0.05396825397f))));
+    v[r] = fabsf(x) < 0.1f ? p : copysignf(t, x);
+  }
+}
+
+// Every MFMA loop of the policy / learner kernels takes its LDS operands in ONE batch before the first MFMA (LDS_ISSUED is a compiler fence: the reads may
+// not sink of the policy / learner kernels it). Left to itself the compiler issued each read right before the MFMA that uses it - read, s_waitcnt
+// lgkmcnt(0), MFMA, 170 - 190 cycles per step instead of the MFMA's 64 (scripts/learn_phases.py: layer 1 7.8 k cycles for 40 steps).
+#define LDS_ISSUED() asm volatile("" ::: "memory")
+
 // row of accumulator register `reg` on a lane of half h = lane >> 5 (C/D layout of the 32x32 MFMA forms)
 __device__ __forceinline__ constexpr int rowmap(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 

@@ -8,12 +8,12 @@
 //                    workgroup, merged IN FIXED ORDER by the last workgroup to end: deterministic) -> Chan's parallel
 //                    update of the running mean / variance (f64 state, as numpy's in VecNormalize), f32 mean / rstd
 //                    for the policy kernel; ret = ret*gamma + rew; ret[done] = 0.
-//   act_kernel       one workgroup = 2 tiles of 32 envs x 2 waves (policy net, value net). The parameter vector (84 KB)
-//                    and the normalised observation tiles are staged in LDS; the 75 -> 64 -> 64 -> {25, 1} tanh MLPs run on the matrix cores with
+//   act_kernel       one workgroup = (tile of 32 envs, net), 2 waves that own half of a hidden layer's neurons each. The net's
+//                    parameters and the normalised observation tile are staged in LDS; the 75 -> 64 -> 64 -> {25, 1} tanh MLPs run on the matrix cores with
 //                    v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: exact f32, the dense contraction of this path)
 //                    in the TRANSPOSED form H^T = W^T X^T: the result tile has the env on the lane and the neurons in
-//                    the 16 accumulator registers, which is exactly the B operand of the next layer's MFMA - the
-//                    activations never leave the registers (no LDS round trip, no barrier between layers).
+//                    the 16 accumulator registers, which is exactly the B operand of the next layer's MFMA - a wave's own
+//                    half never leaves the registers, the other wave's half arrives through LDS (one barrier per layer).
 //                    Weights are stored [in][out]: an A operand is 32 consecutive floats per half wave.
 //
 // plus the rollout's GAE(lambda) and the optimiser step (global-norm clip + TF-form Adam) as one launch each.
@@ -43,168 +43,182 @@ struct ActArgs {
   Layout lay;
 };
 
-// hidden layer in transposed form: out^T[32 u + row][env] = b[..] + sum_k W[k][32 u + row] * in^T[k][env], in^T given as
-// two accumulator tiles (k = 32 t + rowmap(s, h) sits in register s of tile t on the lanes of half h): the B operand
-// of MFMA step (t, s) is the lane's OWN register, and the A operand (from the LDS copy of W) carries the matching k.
-__device__ __forceinline__ void hidden_layer(const float *W, const float *bias, const f32x16 (&in)[2], f32x16 (&out)[2], int col, int h) {
-#pragma unroll
-  for (int u = 0; u < 2; u++) {
-#pragma unroll
-    for (int r = 0; r < 16; r++) out[u][r] = bias[32 * u + rowmap(r, h)];
-  }
-#pragma unroll
-  for (int t = 0; t < 2; t++) {
-#pragma unroll
-    for (int s = 0; s < 16; s++) {
-      const int k = 32 * t + rowmap(s, h);
-      const float b = in[t][s];
-#pragma unroll
-      for (int u = 0; u < 2; u++) {
-        const float a = W[k * HID + 32 * u + col];
-        out[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, out[u], 0, 0, 0);
-      }
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < 2; u++) {
-#pragma unroll
-    for (int r = 0; r < 16; r++) out[u][r] = tanh_fast(out[u][r]);
-  }
+// One workgroup = (tile of 32 envs, net): 2 waves, each owning one HALF of the 64 neurons of a hidden layer (u = wave: 32
+// output rows = one MFMA tile); grid (tiles, 2) = 256 workgroups at 4096 envs - the whole chip (until round 4: 64 workgroups of
+// four waves, a wave running one net of one tile alone: 22.8 us, 176 MFMAs in a row on 64 CUs). The layers are the learner's
+// forward pass (ppo_learner.hip: same operands, same order of accumulation): H^T = W^T X^T, the env on the lane, the neurons
+// in the 16 accumulator registers = the B operand of the next layer; the half the other wave owns arrives through LDS, where
+// every activation tile is parked as [row][env]. Only this net's parameters are staged. No control flow between the first
+// load and the first barrier (a branch around loads costs an s_waitcnt vmcnt(0) at the join): out-of-range lanes read a clamped
+// address and select afterwards.
+constexpr int ACT_UF = 29;             // float4s of theta per thread of the staging trip (128 threads: obs_dim <= 126, actions <= 32)
+constexpr int ACT_UX = 32;             // observation elements per thread (32 rows x <= 128 columns)
+constexpr int ACT_XS = MAXD + 1, ACT_TS = TILE + 1;
+__host__ __device__ inline int act_lds_floats(const Layout &lay) {
+  return ((lay.count + 3) & ~3) + TILE * ACT_XS + 2 * HID * ACT_TS + 32;      // theta image | X | H1, H2 parked | sd per action
 }
-
-// One workgroup = 4 waves = 2 tiles of 32 envs x {policy net, value net}. The whole parameter vector (21 k floats,
-// 84 KB) is copied to LDS once per workgroup with 16-byte loads that are all in flight together - read from L2 inside
-// the MFMA loops, every A operand was a dependent round trip of its own (32 us per launch; 172 MFMAs per wave).
-constexpr int ACT_TILES = 2;
-__global__ __launch_bounds__(256) void act_kernel(ActArgs g) {
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) void act_kernel(ActArgs g) {      // (one wave per SIMD: the whole register file, no spills)
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int net = wave & 1, tile = wave >> 1;          // net 0: policy, 1: value
+  const int tid = threadIdx.x, lane = tid & 63, u = tid >> 6, net = blockIdx.y;      // net 0: policy, 1: value
+  if (g.value_only && net == 0) return;
   const int D = g.lay.D, A = g.lay.A;
   const int Dp8 = (D + 7) & ~7;         // K of the first layer, padded to four MFMA k-steps (k = 2 each); X is zero from column D on
-  float *th = lds;                                       // [count] parameters
-  float *Xall = lds + ((g.lay.count + 3) & ~3);          // [ACT_TILES][TILE][MAXD + 1] normalised observations (+ zero pad)
-  {
-    // (11 loads per thread in flight per trip: left as a plain loop, every 16-byte load waited for its own round trip)
-    const float4 *src = reinterpret_cast<const float4 *>(g.theta);
-    float4 *dst = reinterpret_cast<float4 *>(th);
-    const int n4 = g.lay.count >> 2;
-    for (int i0 = tid; i0 < n4; i0 += 256 * 11) {     // 21 float4 per thread: two trips of 11
-      float4 t[11];
-#pragma unroll
-      for (int u = 0; u < 11; u++) { const int i = i0 + 256 * u; t[u] = src[i < n4 ? i : 0]; }
-#pragma unroll
-      for (int u = 0; u < 11; u++) { const int i = i0 + 256 * u; if (i < n4) dst[i] = t[u]; }
-    }
-    for (int i = (n4 << 2) + tid; i < g.lay.count; i += 256) th[i] = g.theta[i];
-  }
-  // ---- stage the tiles: normalise, clip, keep a copy for the rollout buffer
-  const int eb = blockIdx.x * (ACT_TILES * TILE);
-  constexpr int UX = 10;      // 19 elements per thread at D = 75: two trips
-  for (int idx0 = tid; idx0 < ACT_TILES * TILE * Dp8; idx0 += 256 * UX) {
-    float raw[UX], mean[UX], rstd[UX];
-    int ii[UX], kk[UX];
-    bool ok[UX];
-#pragma unroll
-    for (int u = 0; u < UX; u++) {
-      const int idx = idx0 + 256 * u;
-      ii[u] = idx / Dp8; kk[u] = idx - ii[u] * Dp8;
-      ok[u] = idx < ACT_TILES * TILE * Dp8 && kk[u] < D && eb + ii[u] < g.n;
-      const int kc = kk[u] < D ? kk[u] : 0;
-      raw[u] = ok[u] ? g.rows[(size_t)(eb + ii[u]) * g.row_stride + kc] : 0.f;
-      mean[u] = g.norm[kc]; rstd[u] = g.norm[D + kc];
-    }
-#pragma unroll
-    for (int u = 0; u < UX; u++) {
-      if (idx0 + 256 * u >= ACT_TILES * TILE * Dp8) continue;
-      float x = 0.f;
-      if (ok[u]) {
-        x = fminf(fmaxf((raw[u] - mean[u]) * rstd[u], -g.clip_obs), g.clip_obs);
-        if (g.obs_out && !g.value_only) g.obs_out[(size_t)(eb + ii[u]) * D + kk[u]] = x;
-      }
-      Xall[ii[u] * (MAXD + 1) + kk[u]] = x;
-    }
-  }
-  __syncthreads();
-  if (g.value_only && net == 0) return;
-  const float *X = Xall + tile * TILE * (MAXD + 1);
-  const int e0 = eb + tile * TILE;
+  float *th = lds;                                       // parameters, theta's own layout (the other net's part stays unwritten)
+  float *X = lds + ((g.lay.count + 3) & ~3);             // [TILE][MAXD + 1] normalised observations (+ zero pad)
+  float *H1 = X + TILE * ACT_XS, *H2 = H1 + HID * ACT_TS, *SD = H2 + HID * ACT_TS;
+  const int e0 = blockIdx.x * TILE;
   const int col = lane & 31, h = lane >> 5;
-  const float *W1 = th + (net ? g.lay.vW1 : g.lay.pW1), *b1 = th + (net ? g.lay.vb1 : g.lay.pb1);
-  const float *W2 = th + (net ? g.lay.vW2 : g.lay.pW2), *b2 = th + (net ? g.lay.vb2 : g.lay.pb2);
-  // the sample's noise draws, fetched now: their round trip hides behind the MFMA phases
-  const int e = e0 + col;
+  const int e = e0 + col, ec = e < g.n ? e : g.n - 1;
+  // ---- loads: observation rows, this net's parameters, the noise draws (their round trip hides behind the MFMA phases)
+  float raw[ACT_UX], mean[ACT_UX], rstd[ACT_UX];
+#pragma unroll
+  for (int q = 0; q < ACT_UX; q++) {
+    const int idx = min(tid + 128 * q, TILE * Dp8 - 1), ii = idx / Dp8, kk = idx - ii * Dp8;
+    const int kc = kk < D ? kk : D - 1, er = min(e0 + ii, g.n - 1);
+    raw[q] = g.rows[(size_t)er * g.row_stride + kc];
+    mean[q] = g.norm[kc]; rstd[q] = g.norm[D + kc];
+  }
+  float tpx[ACT_UF], tpy[ACT_UF], tpz[ACT_UF], tpw[ACT_UF];     // (as one float4 array the compiler kept it in scratch)
+  const float4 *s4 = reinterpret_cast<const float4 *>(g.theta);
+  const int lo4 = (net ? g.lay.vW1 : 0) >> 2, hi4 = (net ? g.lay.logstd : g.lay.vW1) >> 2;
+  const int ls4 = g.lay.logstd >> 2, le4 = g.lay.count >> 2;
+  const int n4 = (hi4 - lo4) + (net ? 0 : le4 - ls4);
+  auto theta_src = [&](int q) {          // the float4 of theta that slot q of this thread stages (clamped beyond the last)
+    const int i = tid + 128 * q;
+    const int sq = i < hi4 - lo4 ? lo4 + i : ls4 + (i - (hi4 - lo4));
+    return i < n4 ? sq : lo4;
+  };
+#pragma unroll
+  for (int q = 0; q < ACT_UF; q++) { const float4 t = s4[theta_src(q)]; tpx[q] = t.x; tpy[q] = t.y; tpz[q] = t.z; tpw[q] = t.w; }
+  const float *nzp = g.noise ? g.noise : g.theta;      // (value-only calls pass no noise: any readable float)
   f32x16 nz_in;
 #pragma unroll
   for (int r = 0; r < 16; r++) {
     const int a = rowmap(r, h);
-    nz_in[r] = (net == 0 && !g.value_only && a < A && e < g.n) ? g.noise[(size_t)e * A + a] : 0.f;
+    nz_in[r] = nzp[g.noise ? (size_t)ec * A + (a < A ? a : A - 1) : 0];
   }
-  // ---- layer 1: h1^T = tanh(W1^T x^T + b1); B operand = the observation of env `col` from LDS
-  f32x16 h1[2], h2[2];
+  const float ls_raw = g.theta[g.lay.logstd + (lane < A ? lane : A - 1)];
+  LDS_ISSUED();
+  // ---- stage the tile: normalise, clip, keep a copy for the rollout buffer
 #pragma unroll
-  for (int u = 0; u < 2; u++) {
-#pragma unroll
-    for (int r = 0; r < 16; r++) h1[u][r] = b1[32 * u + rowmap(r, h)];
+  for (int q = 0; q < ACT_UX; q++) {
+    const int idx = tid + 128 * q, ii = idx / Dp8, kk = idx - ii * Dp8;
+    const bool in = idx < TILE * Dp8, ok = in && kk < D && e0 + ii < g.n;
+    const float x = ok ? fminf(fmaxf((raw[q] - mean[q]) * rstd[q], -g.clip_obs), g.clip_obs) : 0.f;
+    if (ok && net == 0 && g.obs_out) g.obs_out[(size_t)(e0 + ii) * D + kk] = x;
+    X[in ? ii * ACT_XS + kk : TILE * ACT_XS - 1] = in ? x : 0.f;         // (the dump slot is a pad column: never read)
   }
-  // four k-steps per trip: their 12 LDS operand reads are issued together, then the 8 MFMAs (one k-step at a time,
-  // every MFMA waited for its own LDS round trip: 3.3 us of the kernel)
-  for (int k0 = 0; k0 < Dp8; k0 += 8) {
-    float a0[4], a1[4], b[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int k = k0 + 2 * j + h;
-      b[j] = X[col * (MAXD + 1) + k];                  // (zero from column D on)
-      const int kc = k < D ? k : D - 1;                // (such a weight row does not exist: any finite value, times 0)
-      a0[j] = W1[kc * HID + col]; a1[j] = W1[kc * HID + 32 + col];
+  for (int q = 0; q < ACT_UF; q++) {
+    if (tid + 128 * q < n4) reinterpret_cast<float4 *>(th)[theta_src(q)] = make_float4(tpx[q], tpy[q], tpz[q], tpw[q]);
+  }
+  if (u == 1 && lane < 32) SD[lane] = lane < A ? expf(ls_raw) : 1.f;       // sd of every action, once per workgroup
+  asm volatile("" : "+v"(nz_in));       // (pinned: the compiler would sink the loads to their use after the last barrier)
+  __syncthreads();
+  const float *W1 = th + (net ? g.lay.vW1 : g.lay.pW1), *b1 = th + (net ? g.lay.vb1 : g.lay.pb1);
+  const float *W2 = th + (net ? g.lay.vW2 : g.lay.pW2), *b2 = th + (net ? g.lay.vb2 : g.lay.pb2);
+  // ---- layer 1 (own half): h1^T = tanh(W1^T x^T + b1); B operand = the observation of env `col` from LDS. All LDS operands
+  // of a chain are read in one batch before its first MFMA (ppo_learner.hip, LDS_ISSUED)
+  f32x16 h1o, h2o;
+#pragma unroll
+  for (int r = 0; r < 16; r++) h1o[r] = b1[32 * u + rowmap(r, h)];
+  {
+    const int nch = Dp8 >> 3;                            // chunks of four k-steps, <= 16
+    float wa[64], xb[64];
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+      if (c < nch) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int k = 8 * c + 2 * j + h;
+          xb[4 * c + j] = X[col * ACT_XS + k];           // (zero from column D on)
+          const int kc = k < D ? k : D - 1;              // (such a weight row does not exist: any finite value, times 0)
+          wa[4 * c + j] = W1[kc * HID + 32 * u + col];
+        }
+      }
     }
+    LDS_ISSUED();
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      h1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b[j], h1[0], 0, 0, 0);
-      h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b[j], h1[1], 0, 0, 0);
+    for (int c = 0; c < 16; c++) {
+      if (c < nch) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) h1o = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[4 * c + j], xb[4 * c + j], h1o, 0, 0, 0);
+      }
     }
   }
+  tanh16(h1o);
 #pragma unroll
-  for (int u = 0; u < 2; u++) {
+  for (int r = 0; r < 16; r++) H1[(32 * u + rowmap(r, h)) * ACT_TS + col] = h1o[r];
+  __syncthreads();
+  // ---- layer 2 (own half; k ascending: t = 0, 1)
 #pragma unroll
-    for (int r = 0; r < 16; r++) h1[u][r] = tanh_fast(h1[u][r]);
+  for (int r = 0; r < 16; r++) h2o[r] = b2[32 * u + rowmap(r, h)];
+  {
+    float wa[32], hb[16];
+#pragma unroll
+    for (int s = 0; s < 32; s++) wa[s] = W2[(32 * (s >> 4) + rowmap(s & 15, h)) * HID + 32 * u + col];
+#pragma unroll
+    for (int s = 0; s < 16; s++) hb[s] = H1[(32 * (1 - u) + rowmap(s, h)) * ACT_TS + col];      // the half the other wave owns
+    LDS_ISSUED();
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      if (t == u) {
+#pragma unroll
+        for (int s = 0; s < 16; s++) h2o = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[16 * t + s], h1o[s], h2o, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 16; s++) h2o = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[16 * t + s], hb[s], h2o, 0, 0, 0);
+      }
+    }
   }
-  // ---- layer 2, activations from registers
-  hidden_layer(W2, b2, h1, h2, col, h);
+  tanh16(h2o);
+  if (u == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) H2[(32 + rowmap(r, h)) * ACT_TS + col] = h2o[r];
+  }
+  __syncthreads();
+  if (u == 1) return;
+  // ---- wave 0: the output layer
   if (net == 1) {
-    // ---- value head: one output; every lane sums its 32 neurons, the two halves of an env meet by a swap
+    // value head: one output; every lane sums its 32 neurons (own half, then the parked half: k ascending), the two halves of an env meet by a swap
     const float *w = th + g.lay.vW3;
     float v = 0.f;
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
+    for (int s = 0; s < 16; s++) v = __builtin_fmaf(h2o[s], w[rowmap(s, h)], v);
 #pragma unroll
-      for (int s = 0; s < 16; s++) v = __builtin_fmaf(h2[t][s], w[32 * t + rowmap(s, h)], v);
-    }
+    for (int s = 0; s < 16; s++) v = __builtin_fmaf(H2[(32 + rowmap(s, h)) * ACT_TS + col], w[32 + rowmap(s, h)], v);
     v += __shfl_xor(v, 32, 64);
     v += th[g.lay.vb3];
     if (h == 0 && e < g.n && g.value_out) g.value_out[e] = v;
     return;
   }
-  // ---- policy head: mean^T[a][env] (a = rowmap(reg, h) < A), then the Gaussian sample and its log-probability
+  // policy head: mean^T[a][env] (a = rowmap(reg, h) < A), then the Gaussian sample and its log-probability
   const float *W3 = th + g.lay.pW3, *b3 = th + g.lay.pb3, *ls = th + g.lay.logstd;
   f32x16 mu;
 #pragma unroll
-  for (int r = 0; r < 16; r++) { const int a = rowmap(r, h); mu[r] = a < A ? b3[a] : 0.f; }
+  for (int r = 0; r < 16; r++) { const int a = rowmap(r, h); mu[r] = b3[a < A ? a : A - 1]; }
 #pragma unroll
-  for (int t = 0; t < 2; t++) {
+  for (int r = 0; r < 16; r++) mu[r] = rowmap(r, h) < A ? mu[r] : 0.f;
+  {
+    float wa[32], hb[16];
 #pragma unroll
-    for (int s = 0; s < 16; s++) {
-      const int k = 32 * t + rowmap(s, h);
-      const float a = col < A ? W3[k * A + col] : 0.f;     // A operand: row = action `col`
-      mu = __builtin_amdgcn_mfma_f32_32x32x2f32(a, h2[t][s], mu, 0, 0, 0);
-    }
+    for (int s = 0; s < 32; s++) wa[s] = W3[(32 * (s >> 4) + rowmap(s & 15, h)) * A + (col < A ? col : A - 1)];      // A operand: row = action `col`
+#pragma unroll
+    for (int s = 0; s < 16; s++) hb[s] = H2[(32 + rowmap(s, h)) * ACT_TS + col];
+    LDS_ISSUED();
+#pragma unroll
+    for (int s = 0; s < 32; s++) wa[s] = col < A ? wa[s] : 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; s++) mu = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[s], h2o[s], mu, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 16; s++) mu = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[16 + s], hb[s], mu, 0, 0, 0);
   }
   float zz = 0.f, sum_ls = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; r++) {
     const int a = rowmap(r, h);
     if (a < A) {
-      const float l = ls[a], sd = expf(l);
+      const float l = ls[a], sd = SD[a];
       sum_ls += l;
       if (e < g.n) {
         const float nz = nz_in[r];
@@ -572,8 +586,8 @@ int trex_policy_act(TrexPolicy *p, const float *theta_dev, const float *rows_dev
   BUF_TRY(value_out, n * sizeof(float), "trex_policy_act: value_out");
   ActArgs a{theta_dev, rows_dev, p->norm, noise_dev, actions_dev, obs_out, act_out, logp_out, value_out,
             p->n, row_stride, value_only ? 1 : 0, clip_obs, p->lay};
-  const size_t lds_bytes = (((size_t)p->lay.count + 3) & ~(size_t)3) * sizeof(float) + (size_t)ACT_TILES * TILE * (MAXD + 1) * sizeof(float);
-  hipLaunchKernelGGL(act_kernel, dim3((p->n + ACT_TILES * TILE - 1) / (ACT_TILES * TILE)), dim3(256), lds_bytes, (hipStream_t)stream, a);
+  const size_t lds_bytes = (size_t)act_lds_floats(p->lay) * sizeof(float);
+  hipLaunchKernelGGL(act_kernel, dim3((p->n + TILE - 1) / TILE, 2), dim3(128), lds_bytes, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
   return TREX_OK;
 }

@@ -30,11 +30,6 @@
 
 namespace {
 
-// Every MFMA loop below takes its LDS operands in ONE batch before the first MFMA (LDS_ISSUED is a compiler fence: the reads may
-// not sink below it). Left to itself the compiler issued each read right before the MFMA that uses it - read, s_waitcnt
-// lgkmcnt(0), MFMA, 170 - 190 cycles per step instead of the MFMA's 64 (scripts/learn_phases.py: layer 1 7.8 k cycles for 40 steps).
-#define LDS_ISSUED() asm volatile("" ::: "memory")
-
 constexpr int LEARN_UF = 13;           // float4s of theta per thread of learn_grad_kernel's staging trip
 constexpr int W2S = HID + 1;           // LDS row stride of W2 (transposed reads in the backward pass)
 constexpr int XS = MAXD + 1;           // LDS row stride of the observation tile
@@ -73,23 +68,6 @@ struct LearnArgs {
   float cliprange, vf_coef;
   Layout lay;
 };
-
-// tanh_fast (policy_common.h) of 16 accumulator registers, stage by stage: the two quarter-rate transcendentals of one value
-// overlap with those of the others (one value after the other the chain of each costs ~165 cycles: profiles/tools/mfma_chain_bench.hip)
-__device__ __forceinline__ void tanh16(f32x16 &v) {
-  float e[16];
-#pragma unroll
-  for (int r = 0; r < 16; r++) e[r] = __builtin_amdgcn_exp2f(fabsf(v[r]) * 2.885390081777927f);
-#pragma unroll
-  for (int r = 0; r < 16; r++) e[r] = __builtin_amdgcn_rcpf(e[r] + 1.0f);
-#pragma unroll
-  for (int r = 0; r < 16; r++) {
-    const float x = v[r], x2 = x * x;
-    const float t = 1.0f - 2.0f * e[r];
-    const float p = x * (1.0f + x2 * (-0.3333333333f + x2 * (0.1333333333f + x2 * (-0.05396825397f))));
-    v[r] = fabsf(x) < 0.1f ? p : copysignf(t, x);
-  }
-}
 
 // sum over the 32 lanes of a half wave (same h), result on all of them: four DPP steps inside the 16-lane rows, then
 // gfx950's v_permlane16_swap (rows 0<->1, 2<->3)
