@@ -18,6 +18,12 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS --output-format csv -d $OUT/sq2 -- python bench.py --steps 40 --warmup 30 --no-cpu-baseline > $OUT/bench_sq2.json 2> $OUT/bench_sq2.err || echo "SQ2 pass failed"
 TREX_LIB=$PWD/trex-gym_amd/trex_gym/libtrex_hip_stamps.so python scripts/wave_phases.py 4096 1300 0 2>&1 | grep -v amdgpu.ids > $OUT/wave_phases_4096.txt
 TREX_LIB=$PWD/trex-gym_amd/trex_gym/libtrex_hip_stamps.so python scripts/wave_phases.py 256 1300 0 2>&1 | grep -v amdgpu.ids > $OUT/wave_phases_256.txt
+# the pair launch (two envs per workgroup, the product's step launch up to 4096 envs) and the learner, stamped (diagnostic builds)
+TREX_LIB=$PWD/trex-gym_amd/trex_gym/libtrex_hip_pstamps.so python scripts/wave_phases_pair.py 4096 1300 2>&1 | grep -v amdgpu.ids > $OUT/wave_phases_pair_4096.txt || echo "pair stamps failed"
+TREX_LIB=$PWD/trex-gym_amd/trex_gym/libtrex_hip_pstamps.so python scripts/wave_phases_pair.py 256 1300 2>&1 | grep -v amdgpu.ids > $OUT/wave_phases_pair_256.txt || true
+TREX_LIB=$PWD/trex-gym_amd/trex_gym/libtrex_hip_lstamps.so python scripts/learn_phases.py 2>&1 | grep -v amdgpu.ids > $OUT/learn_phases.txt || echo "learner stamps failed"
+bash scripts/profile_ppo_kernels.sh $OUT/ppo_kernels.md > /dev/null 2>&1 || echo "ppo kernel table failed"
+./profiles/tools/launch_floor_bench > $OUT/launch_floor.txt 2>&1 || true
 python scripts/parity_stats.py 2>&1 | grep -v amdgpu.ids > $OUT/parity_stats.txt
 python scripts/ppo_rate.py 4 2>&1 | grep PPO > $OUT/ppo_rate.txt
 python scripts/ppo_rate.py 32 2>&1 | grep PPO >> $OUT/ppo_rate.txt
@@ -28,6 +34,11 @@ python scripts/soak.py 20000 2>&1 | grep -v amdgpu.ids > $OUT/soak.txt || echo "
 ./profiles/tools/row_bench > $OUT/row_bench.txt 2>&1 || true
 ./profiles/tools/census 4096 > $OUT/census.txt 2>&1 || true
 # summarise on the box (the raw traces are too big to travel), keep only gpurun_out/prof/final
+python scripts/refresh_profiles.py ${1:-r03} $OUT/final
+# the two headline lines once more, now that the traffic of THIS build is known (bench.py reads profiles/pmc_traffic.json)
+cp $OUT/final/pmc_traffic.json $OUT/final/sq_counters.json profiles/
+python bench.py --steps 300 --warmup 30 > $OUT/bench_300.json 2> $OUT/bench_300.err
+python bench.py --steps 20 --warmup 5 > $OUT/bench_20.json 2> $OUT/bench_20.err
 python scripts/refresh_profiles.py ${1:-r03} $OUT/final
 rm -rf $OUT/trace $OUT/sq $OUT/sq2 gpurun_out/pmc
 ls $OUT/final

@@ -101,6 +101,8 @@ for src, dst in (("bench_300.json", "bench_line.json"), ("bench_256.json", "benc
                  ("soak.txt", "soak.txt"), ("ppo_learning_curve.txt", "ppo_learning_curve.txt"),
                  ("bench_300_spl10.json", "bench_line_steps_per_launch10.json"), ("bench_300_spl30.json", "bench_line_steps_per_launch30.json"),
                  ("wave_phases_4096.txt", "wave_phases_4096.txt"), ("wave_phases_256.txt", "wave_phases_256.txt"),
+                 ("wave_phases_pair_4096.txt", "wave_phases_pair_4096.txt"), ("wave_phases_pair_256.txt", "wave_phases_pair_256.txt"),
+                 ("learn_phases.txt", "learn_phases.txt"), ("ppo_kernels.md", "ppo_kernels.md"), ("launch_floor.txt", "launch_floor.txt"),
                  ("row_bench.txt", "row_bench.txt"), ("census.txt", "census.txt")):
     if os.path.exists(P + "/" + src):
         shutil.copy(P + "/" + src, "%s/%s_%s" % (out, tag, dst))
