@@ -432,6 +432,12 @@ static void finish_row(const Model *m, Work *k, Row *r, const real *vgen, real t
   r->lambda = 0;
 }
 
+#ifdef ORACLE_ROWS_HOOK
+typedef void (*oracle_rows_hook_t)(int nr, const double *B, const double *rowdata, double friction);
+static oracle_rows_hook_t oracle_rows_hook = 0;
+__attribute__((visibility("default"))) void oracle_set_rows_hook(oracle_rows_hook_t f) { oracle_rows_hook = f; }
+#endif
+
 /* One physics substep = one pybullet stepSimulation() at dt (trex_env.py:150). target[] is the
  * position-motor target per BODY index (ignored when !motors_on). */
 static void substep(const Model *m, State *s, const real *target) {
@@ -546,6 +552,23 @@ static void substep(const Model *m, State *s, const real *target) {
     }
   }
 
+#ifdef ORACLE_ROWS_HOOK
+  /* study builds only (scripts/matrix_sweep_proto.py): hands the substep's constraint system to a callback - the Delassus
+   * operator in the residual form of the GPU kernel, B[s][r] = -(J_s . W_r) / diag_s, and per row rhs, bounds, kind, friction_of */
+  if (oracle_rows_hook) {
+    static double hB[MAXROWS * MAXROWS], hrow[MAXROWS * 6];
+    for (int a = 0; a < nr; a++) {
+      for (int b = 0; b < nr; b++) {
+        double t = 0;
+        for (int c = 0; c < nd; c++) t += (double)rows[a].J[c] * (double)rows[b].W[c];
+        hB[a * nr + b] = -t * (double)rows[a].inv_diag;
+      }
+      hrow[6 * a] = (double)rows[a].rhs; hrow[6 * a + 1] = (double)rows[a].lo; hrow[6 * a + 2] = (double)rows[a].hi;
+      hrow[6 * a + 3] = rows[a].kind; hrow[6 * a + 4] = rows[a].friction_of; hrow[6 * a + 5] = rows[a].joint;
+    }
+    oracle_rows_hook(nr, hB, hrow, (double)s->friction);
+  }
+#endif
   /* ---- projected Gauss-Seidel on the velocity level */
   real dv[NDOF_MAX];
   for (int c = 0; c < nd; c++) dv[c] = 0;

@@ -73,6 +73,14 @@ __global__ __launch_bounds__(64) void k(float *out, long long *cyc, int sweeps, 
         const float sd = rl(d, L);
         y = __builtin_fmaf(B[j], sd, y);
         lam += (vs == L) ? d : 0.f;
+      } else if (VARIANT == 17) {
+        // the short row of the speculative motor block: no clamp - writelane (capture of the row before), readlane of y, s_nop 1, fmac (4 slots)
+        asm volatile("v_writelane_b32 %1, %2, %4\n\tv_readlane_b32 %2, %0, %4\n\ts_nop 1\n\tv_fmac_f32_e32 %0, %2, %3"
+                     : "+v"(y), "+v"(dv), "+s"(sprev) : "v"(B[j]), "n"(1 + (j % 63)));
+      } else if (VARIANT == 18) {
+        // the same with s_nop 0 in the place of the capture
+        asm volatile("s_nop 0\n\tv_readlane_b32 %2, %0, %4\n\ts_nop 1\n\tv_fmac_f32_e32 %0, %2, %3"
+                     : "+v"(y), "+v"(dv), "+s"(sprev) : "v"(B[j]), "n"(1 + (j % 63)));
       } else if ((VARIANT >= 8 && VARIANT <= 12) || VARIANT == 16) {
         // hand-placed rows of the round-2 kernel: bounds shifted by the impulse, d = med3(y, blo, bhi); the impulse
         // changes are captured in `dv` (lane L) by v_writelane and committed after the sweep
@@ -171,6 +179,8 @@ int main() {
   run<7>("7 short chain, bounds from lam", out, cyc, sweeps);
   run<12>("12 asm, 7 slots (add med3 sub wl rl nop1 fmac)", out, cyc, sweeps);
   run<8>("8 asm, 5 slots (med3 wl rl nop1 fmac)", out, cyc, sweeps);
+  run<17>("17 asm, 4 slots, no clamp (wl rl nop1 fmac)", out, cyc, sweeps);
+  run<18>("18 asm, 4 slots, no clamp, no capture (nop0 rl nop1 fmac)", out, cyc, sweeps);
   run<16>("16 the same (8) with EXEC = the low 32 lanes", out, cyc, sweeps);
   run<9>("9 asm, 5 slots, s_nop 0 for the writelane", out, cyc, sweeps);
   run<10>("10 asm, 6 slots, s_nop 0 x2 for s_nop 1", out, cyc, sweeps);
